@@ -1,0 +1,200 @@
+/*
+ * tdn.h — C ABI of libtdn.so, the MI355X (gfx950) native hot path behind the
+ * Torch_Detection module registry.
+ *
+ * The reference (TCGGroup/Torch_Detection) has NO native interface: every hot
+ * operation is a torch.nn call made from Python.  Each entry point below names
+ * the reference call site (file:line, relative to the reference root) whose
+ * arithmetic it replaces.  The only intended binder is ctypes from
+ * torch_detection_amd/_lib.py (see INTEGRATION.md for the stub a reference
+ * maintainer would add).
+ *
+ * Conventions
+ *   - All tensors are caller-owned device memory (PyTorch allocations).  The
+ *     library never allocates, frees or synchronises; every kernel is enqueued
+ *     on the hipStream_t passed as `stream` (void*; NULL = default stream).
+ *   - Activations / gradients are NHWC ("channels last"), dtype TDN_BF16
+ *     (2-byte bfloat16).  Weights are pre-packed K-major by tdn_pack_conv_weight.
+ *   - Return value: 0 = ok, negative = error; tdn_last_error() returns a
+ *     thread-local message.  Nothing throws across the boundary.
+ *   - Re-entrant: no global mutable state besides the thread-local error text.
+ */
+#ifndef TDN_H_
+#define TDN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDN_VERSION 100 /* 0.1.0 */
+
+enum { TDN_BF16 = 0 };
+
+/* epilogue addend modes */
+enum {
+  TDN_ADD_NONE = 0,
+  TDN_ADD_SAME = 1,     /* addend has the output's shape (residual `out += residual`, resnet.py:57,117) */
+  TDN_ADD_UP2X = 2,     /* addend is the 2x coarser map, nearest-upsampled (fpn.py:99-101)                */
+  TDN_ADD_SUMPOOL2 = 3  /* addend is the 2x finer map, 2x2 sum-pooled (adjoint of fpn.py:99-101)         */
+};
+
+/* Fused epilogue applied to the fp32 accumulator of a conv / dgrad GEMM:
+ *   v = acc * scale[c] + shift[c]          (eval-mode BatchNorm2d folded, layers.py:50-54; or conv bias, layers.py:93)
+ *   v += addend(...)                        (see modes above)
+ *   if relu:      v = max(v, 0)             (nn.ReLU, resnet.py:35,90,217)
+ *   if mask_src:  v = mask_src > 0 ? v : 0  (adjoint of that ReLU, from the saved forward output)
+ *   out = (bf16) v          (or fp32 when out_f32 != 0: pre-rounding value, used for 1e-3 parity checks
+ *                             and for fp32 module outputs)
+ */
+typedef struct tdn_epilogue {
+  const float* scale;    /* [Cout] or NULL (= 1) */
+  const float* shift;    /* [Cout] or NULL (= 0) */
+  const void* addend;    /* NHWC, Cout channels, or NULL */
+  int32_t addend_mode;   /* TDN_ADD_* */
+  int32_t addend_h;      /* spatial size of the addend tensor (UP2X / SUMPOOL2) */
+  int32_t addend_w;
+  int32_t relu;          /* 0 / 1 */
+  const void* mask_src;  /* NHWC, same shape as the output, or NULL */
+  int32_t out_f32;       /* 0: out is bf16 NHWC; 1: out is float32 NHWC */
+  int32_t reserved;
+} tdn_epilogue;
+
+const char* tdn_last_error(void);
+int tdn_version(void);
+
+/* ---- weight / norm preparation ------------------------------------------------ */
+
+/* Eval-mode BatchNorm2d folded to a per-channel affine (layers.py:50-54, resnet.py:270-276):
+ *   invstd = 1/sqrt(var+eps); scale = gamma*invstd; shift = beta - mean*scale. */
+int tdn_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                float eps, int C, float* scale, float* shift, float* invstd, void* stream);
+
+/* Pack an nn.Conv2d weight (layers.py:12,25,40,93) for the GEMM kernels.
+ *   w: fp32, logical [Cout][Cin][kh][kw] with element strides (s_o, s_i, s_h, s_w).
+ *   w_fwd:   bf16 [Cout][kh][kw][Cin]                       (forward / wgrad-finalize operand)
+ *   w_dgrad: bf16 [Cin][kh][kw][Cout] = scale[co] * w      (may be NULL; dgrad operand, BN scale folded)
+ */
+int tdn_pack_conv_weight(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w,
+                         int Cout, int Cin, int kh, int kw, const float* scale,
+                         void* w_fwd, void* w_dgrad, int dtype, void* stream);
+
+/* Stem variant (conv7x7_group(3,64,stride=2), resnet.py:214): w fp32 [64][3][7][7] contiguous ->
+ * bf16 [Cout][7][8][4] (kw padded 7->8, channels padded 3->4, pads zero). */
+int tdn_pack_stem_weight(const float* w, int Cout, void* w_fwd, int dtype, void* stream);
+
+/* ---- convolution (nn.Conv2d.forward via resnet.py:42-59,97-119,253-258; fpn.py:92-108) ---- */
+
+/* y[N][Ho][Wo][Cout] = epilogue(conv(x[N][H][W][Cin], w_fwd)), square kernel k in {1,3},
+ * stride in {1,2}, pad = k/2 (conv1x1_group / conv3x3_group / ConvModule of the hot path).
+ * Requires Cin % 64 == 0 and Cout % 64 == 0. */
+int tdn_conv2d_fwd(const void* x, const void* w_fwd, void* y, int N, int H, int W, int Cin,
+                   int Cout, int k, int stride, int pad, const tdn_epilogue* ep, int dtype,
+                   void* stream);
+
+/* dx[N][H][W][Cin] = epilogue(conv_transpose(g[N][Ho][Wo][Cout], w_dgrad)) — input gradient of
+ * the conv above (autograd of nn.Conv2d; no explicit reference line: the reference never calls
+ * backward). */
+int tdn_conv2d_dgrad(const void* g, const void* w_dgrad, void* dx, int N, int H, int W, int Cin,
+                     int Cout, int k, int stride, int pad, const tdn_epilogue* ep, int dtype,
+                     void* stream);
+
+/* Workspace bytes tdn_conv2d_wgrad needs for this shape. */
+int64_t tdn_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int k, int stride,
+                                    int pad);
+
+/* Weight / affine gradients of  y = (conv(x, w)) * scale + shift  given g = dL/d(y pre-activation):
+ *   dw[Cout][kh][kw][Cin] (fp32; channels_last view of the nn.Conv2d grad)  = beta*dw + scale * (g^T im2col(x))
+ *   BN mode (mean, invstd != NULL): dgamma = beta*dgamma + invstd*(sum_k w*G - mean*sum_m g), dbeta = beta*dbeta + sum_m g
+ *   bias mode (mean == NULL):       dbeta (= dbias) = beta*dbeta + sum_m g ; dgamma ignored (may be NULL)
+ * scale may be NULL (= 1). */
+int tdn_conv2d_wgrad(const void* x, const void* g, const void* w_fwd, const float* scale,
+                     const float* mean, const float* invstd, float* dw, float* dgamma,
+                     float* dbeta, float beta, int N, int H, int W, int Cin, int Cout, int k,
+                     int stride, int pad, void* workspace, int64_t workspace_bytes, int dtype,
+                     void* stream);
+
+/* ---- stem (resnet.py:214-218,254-258) ------------------------------------------ */
+
+/* NCHW image (fp32, arbitrary element strides) -> zero-padded NHWC4 bf16 staging buffer
+ * xp[N][H+6][W+8][4] (3 px halo top/left/bottom, 3+2 right; channel 3 = 0).  This is the
+ * device-side form of the pad/transpose of dataset_transforms.py:37-44. */
+int tdn_stage_image(const float* img, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N,
+                    int H, int W, void* xp, int dtype, void* stream);
+
+/* y[N][H/2][W/2][64] = relu(bn(conv7x7 s2 p3 (img)))  from the staged image. H, W even. */
+int tdn_stem_conv_fwd(const void* xp, const void* w_stem, void* y, int N, int H, int W, int Cout,
+                      const tdn_epilogue* ep, int dtype, void* stream);
+
+int64_t tdn_stem_conv_wgrad_workspace(int N, int H, int W, int Cout);
+
+/* dw fp32 [Cout][3][7][7] contiguous (+ BN grads as in tdn_conv2d_wgrad). */
+int tdn_stem_conv_wgrad(const void* xp, const void* g, const void* w_stem, const float* scale,
+                        const float* mean, const float* invstd, float* dw, float* dgamma,
+                        float* dbeta, float beta, int N, int H, int W, int Cout, void* workspace,
+                        int64_t workspace_bytes, int dtype, void* stream);
+
+/* ---- pooling / resampling -------------------------------------------------------- */
+
+/* nn.MaxPool2d(3, stride=2, padding=1) (resnet.py:218,258) on NHWC; idx[N][Ho][Wo][C] (uint8) records
+ * the window position (kh*3+kw) of the first maximum, PyTorch's tie rule. C % 8 == 0. */
+int tdn_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C,
+                         int dtype, void* stream);
+
+/* dx[N][H][W][C] = relu_mask(x) * scatter(dy by idx): adjoint of maxpool (and, when mask_src != NULL,
+ * of the in-place ReLU before it, resnet.py:257). */
+int tdn_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, const void* mask_src, void* dx, int N,
+                         int H, int W, int C, int dtype, void* stream);
+
+/* F.max_pool2d(x, 1, stride=2) (fpn.py:116): y[N][ceil(H/2)][ceil(W/2)][C] = x[:, ::2, ::2, :]. */
+int tdn_subsample2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype,
+                       void* stream);
+
+/* dx = dx_in (may be NULL = 0) + scatter(dy) : adjoint of the above, fused with the accumulation. */
+int tdn_subsample2_bwd(const void* dy, const void* dx_in, void* dx, int N, int H, int W, int C,
+                       int dtype, void* stream);
+
+/* out = (a (+ b)) masked by mask_src > 0  (b, mask_src may be NULL). Element-wise, n elements, n % 8 == 0. */
+int tdn_add_relu_mask(const void* a, const void* b, const void* mask_src, void* out, int64_t n,
+                      int dtype, void* stream);
+
+/* bf16 NHWC <-> fp32 NCHW (logical, element strides) boundary converters. */
+int tdn_nchw_f32_to_nhwc(const float* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w,
+                         int N, int C, int H, int W, void* dst, int dtype, void* stream);
+int tdn_nhwc_to_nchw_f32(const void* src, int N, int C, int H, int W, float* dst, int dtype,
+                         void* stream);
+
+/* ---- box ops (absent from the reference: core/__init__.py is empty; semantics = SURVEY Appendix B,
+ *      conventions pinned by datasets/utils/bbox.py:39,375-377 and dataset_transforms.py:120-131) ---- */
+
+/* anchors[(y*featW + x)*A + a][4] = base[a] + (x*stride, y*stride, x*stride, y*stride);
+ * valid[...] = x < valid_w && y < valid_h (uint8, may be NULL). */
+int tdn_anchor_grid(const float* base_anchors, int A, int featH, int featW, int stride,
+                    int valid_h, int valid_w, float* anchors, uint8_t* valid, void* stream);
+
+/* iou[N][M] (fp32) of inclusive-pixel xyxy boxes, '+1' convention, IEEE fp32 (no contraction). */
+int tdn_bbox_iou_pairwise(const float* a, int N, const float* b, int M, float* iou, void* stream);
+
+int64_t tdn_nms_workspace(int N);
+
+/* Greedy NMS: stable sort by score desc (ties: lower index first), suppress iou > thr.
+ *   keep[N] uint8 (original order), kept_idx[N] int64 (score order, first *num_kept valid),
+ *   num_kept: device int32. */
+int tdn_nms(const float* boxes, const float* scores, int N, float iou_thr, uint8_t* keep,
+            int64_t* kept_idx, int32_t* num_kept, void* workspace, int64_t workspace_bytes,
+            void* stream);
+
+/* ---- host-only introspection (no GPU needed; used by CPU tests) --------------------- */
+
+/* Describes the GEMM decomposition the library would launch for a conv: fills out[0..15] with
+ * {M, Ngemm, Kgemm, BM, BN, BK, grid_x, grid_y, grid_z, nclasses, ntaps(class0), splitk, ...}.
+ * kind: 0 = fwd, 1 = dgrad, 2 = wgrad. */
+int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                    int32_t* out16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDN_H_ */

@@ -1,0 +1,235 @@
+"""oracle/gen_golden.py — generate tests/golden/* by importing the reference on PyTorch-CPU.
+
+TEST INFRASTRUCTURE ONLY.  This is the ONLY file that imports /root/reference; it runs in the build
+container (the reference never travels to the GPU box).  It
+  1. imports the reference with third-party shims (none modifies reference code):
+     sys.path first, collections.Sequence/Mapping aliases, stub cv2 / pycocotools modules;
+  2. asserts that oracle/torch_ref.py is BIT-EQUAL to the imported reference (ResNet-18/50/101 + FPN,
+     forward and parameter/input gradients) on fp32 CPU;
+  3. writes small golden vectors (inputs are regenerated from tests/golden_util.py, outputs are stored).
+Run:  python oracle/gen_golden.py
+"""
+import collections
+import collections.abc
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    sys.path.insert(0, "/root/reference")
+    collections.Sequence = collections.abc.Sequence
+    collections.Mapping = collections.abc.Mapping
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    pc = types.ModuleType("pycocotools")
+    pcc = types.ModuleType("pycocotools.coco")
+    pcc.COCO = object
+    sys.modules.setdefault("pycocotools", pc)
+    sys.modules.setdefault("pycocotools.coco", pcc)
+    import models.backbone  # noqa: F401
+    import models.necks  # noqa: F401
+    from models.registry import BACKBONES, NECKS
+    import models.backbone.resnet as ref_resnet
+    return BACKBONES, NECKS, ref_resnet
+
+
+def manifest_of(m):
+    return [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    BACKBONES, NECKS, ref_resnet = import_reference()
+    from oracle import torch_ref as O
+    from golden_util import det_tensor, fill_state_dict
+
+    RefResNet = BACKBONES.module_dict["ResNet"]
+    RefFPN = NECKS.module_dict["FPN"]
+    os.makedirs(GOLD, exist_ok=True)
+    man = {"registry": {"backbone": sorted(BACKBONES.module_dict), "neck": sorted(NECKS.module_dict)}}
+
+    # ---- (1) state_dict manifests -------------------------------------------------------------
+    for d in (18, 50, 101):
+        man["resnet%d" % d] = manifest_of(RefResNet(d))
+    man["fpn_r50"] = manifest_of(RefFPN([256, 512, 1024, 2048], 256, 5))
+    man["fpn_r18"] = manifest_of(RefFPN([64, 128, 256, 512], 256, 5))
+
+    # ---- (5) train() semantics ---------------------------------------------------------------
+    m = RefResNet(18)
+    ret = m.train()
+    man["train_semantics"] = {
+        "train_returns_none": ret is None,
+        "all_bn_eval_after_train": all(not x.training for x in m.modules() if isinstance(x, torch.nn.BatchNorm2d)),
+        "all_params_require_grad": all(p.requires_grad for p in m.parameters()),
+        "feat_dim": {str(d): RefResNet(d).feat_dim for d in (18, 50, 101)},
+    }
+    try:
+        RefResNet(20)
+        man["bad_depth_error"] = None
+    except KeyError as e:
+        man["bad_depth_error"] = "KeyError:" + str(e)
+    try:
+        RefResNet(18).init_weights(pretrained=3)
+        man["bad_pretrained_error"] = None
+    except TypeError as e:
+        man["bad_pretrained_error"] = "TypeError:" + str(e)
+
+    # ---- (2) config 1: ResNet-18, 1x3x224x224 -------------------------------------------------
+    m = RefResNet(18)
+    sd = fill_state_dict(m.state_dict(), 18)
+    m.load_state_dict(sd)
+    m.train()  # BN -> eval per reference default (resnet.py:270-276)
+    x = det_tensor((1, 3, 224, 224), 1001, -2.0, 2.0)
+    with torch.no_grad():
+        ref = m(x)
+        mine = O.resnet_forward(sd, x, 18)
+    for a, b in zip(ref, mine):
+        assert torch.equal(a, b), "oracle != reference (R18 forward)"
+    np.savez_compressed(os.path.join(GOLD, "resnet18_c1.npz"), **{"c%d" % (i + 2): t.numpy() for i, t in enumerate(ref)})
+    man["resnet18_c1"] = {"input": {"shape": [1, 3, 224, 224], "seed": 1001, "lo": -2.0, "hi": 2.0},
+                          "state_seed": 18, "out_shapes": [list(t.shape) for t in ref]}
+
+    # R50 / R101 bit-equality at a small padded size (not stored: weights too large; checksums only)
+    for d, seed in ((50, 50), (101, 101)):
+        m = RefResNet(d)
+        sd = fill_state_dict(m.state_dict(), seed)
+        m.load_state_dict(sd)
+        m.train()
+        x = det_tensor((1, 3, 64, 96), 2000 + d, -2.0, 2.0)
+        with torch.no_grad():
+            ref = m(x)
+            mine = O.resnet_forward(sd, x, d)
+        for a, b in zip(ref, mine):
+            assert torch.equal(a, b), "oracle != reference (R%d forward)" % d
+        man["resnet%d_small" % d] = {
+            "input": {"shape": [1, 3, 64, 96], "seed": 2000 + d, "lo": -2.0, "hi": 2.0}, "state_seed": seed,
+            "sum": [float(t.double().sum()) for t in ref], "abssum": [float(t.double().abs().sum()) for t in ref]}
+
+    # ---- (3) residual blocks: fwd + all grads ----------------------------------------------------
+    blocks = {}
+    cases = {
+        "bottleneck_s1_nodown": (ref_resnet.Bottleneck, 256, 64, 1, (2, 10, 12)),
+        "bottleneck_s1_down": (ref_resnet.Bottleneck, 64, 64, 1, (2, 10, 12)),
+        "bottleneck_s2_down": (ref_resnet.Bottleneck, 128, 64, 2, (2, 9, 12)),
+        "basic_s1": (ref_resnet.BasicBlock, 64, 64, 1, (2, 10, 12)),
+        "basic_s2_down": (ref_resnet.BasicBlock, 64, 128, 2, (2, 10, 11)),
+    }
+    for ci, (name, (cls, inpl, planes, stride, (n, h, w))) in enumerate(sorted(cases.items())):
+        blk = ref_resnet._make_res_layer(cls, inpl, planes, 1, stride=stride)[0]
+        sd = fill_state_dict(blk.state_dict(), 300 + ci)
+        blk.load_state_dict(sd)
+        blk.eval()
+        x = det_tensor((n, inpl, h, w), 400 + ci, -1.0, 1.0).requires_grad_(True)
+        y = blk(x)
+        dy = det_tensor(tuple(y.shape), 500 + ci, -1.0, 1.0)
+        y.backward(dy)
+        # oracle check (fwd + grads, bit-equal)
+        kind = _basic = cls is ref_resnet.BasicBlock
+        fn = O._basic_block if kind else O._bottleneck
+        ps = {("b." + k): v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k)
+              for k, v in sd.items()}
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = fn(x2, ps, "b", stride, 1, blk.downsample is not None)
+        y2.backward(dy)
+        assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad), "oracle != reference (%s)" % name
+        for k, p in blk.named_parameters():
+            assert torch.equal(ps["b." + k].grad, p.grad), "oracle grad != reference (%s %s)" % (name, k)
+        blocks[name + "/y"] = y.detach().numpy()
+        blocks[name + "/dx"] = x.grad.numpy()
+        for k, p in blk.named_parameters():
+            blocks[name + "/grad/" + k] = p.grad.numpy()
+        man.setdefault("blocks", {})[name] = {
+            "cls": cls.__name__, "inplanes": inpl, "planes": planes, "stride": stride, "x_shape": [n, inpl, h, w],
+            "state_seed": 300 + ci, "x_seed": 400 + ci, "dy_seed": 500 + ci,
+            "state_keys": manifest_of(blk)}
+    np.savez_compressed(os.path.join(GOLD, "blocks.npz"), **blocks)
+
+    # ---- (4) FPN: fwd + input grads + param grads; and the odd-size failure ----------------------
+    chans = [64, 128, 256, 512]
+    sizes = [(16, 24), (8, 12), (4, 6), (2, 3)]
+    fpn = RefFPN(chans, 64, 5)
+    sd = fill_state_dict(fpn.state_dict(), 600)
+    fpn.load_state_dict(sd)
+    ins = [det_tensor((2, c, h, w), 610 + i, -1.0, 1.0).requires_grad_(True) for i, (c, (h, w)) in
+           enumerate(zip(chans, sizes))]
+    outs = fpn(ins)
+    cots = [det_tensor(tuple(o.shape), 620 + i, -1.0, 1.0) for i, o in enumerate(outs)]
+    torch.autograd.backward(outs, cots)
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    ins2 = [t.detach().clone().requires_grad_(True) for t in ins]
+    outs2 = O.fpn_forward(ps, ins2, 5)
+    torch.autograd.backward(outs2, cots)
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b), "oracle != reference (FPN forward)"
+    for a, b in zip(ins, ins2):
+        assert torch.equal(a.grad, b.grad), "oracle != reference (FPN input grad)"
+    for k, p in fpn.named_parameters():
+        assert torch.equal(ps[k].grad, p.grad), "oracle != reference (FPN grad %s)" % k
+    f = {}
+    for i, o in enumerate(outs):
+        f["out%d" % i] = o.detach().numpy()
+    for i, t in enumerate(ins):
+        f["din%d" % i] = t.grad.numpy()
+    for k, p in fpn.named_parameters():
+        f["grad/" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, "fpn.npz"), **f)
+    man["fpn_small"] = {"in_channels": chans, "out_channels": 64, "num_outs": 5, "sizes": [list(s) for s in sizes],
+                        "N": 2, "state_seed": 600, "in_seed0": 610, "cot_seed0": 620,
+                        "out_shapes": [list(o.shape) for o in outs]}
+    # failure case: a level that is not exactly 2x the next (fpn.py:99-101) raises
+    bad = [det_tensor((1, c, h, w), 1, -1, 1) for c, (h, w) in zip(chans, [(16, 24), (8, 11), (4, 6), (2, 3)])]
+    try:
+        fpn(bad)
+        man["fpn_odd_size_error"] = None
+    except RuntimeError as e:
+        man["fpn_odd_size_error"] = "RuntimeError"
+        man["fpn_odd_size_error_msg"] = str(e)[:120]
+    try:
+        fpn(ins[:3])
+        man["fpn_wrong_len_error"] = None
+    except AssertionError:
+        man["fpn_wrong_len_error"] = "AssertionError"
+
+    # ---- R50+FPN end-to-end fwd+bwd oracle == reference (small, not stored) ----------------------
+    rb = RefResNet(50)
+    rf = RefFPN([256, 512, 1024, 2048], 256, 5)
+    sdb = fill_state_dict(rb.state_dict(), 50)
+    sdf = fill_state_dict(rf.state_dict(), 51)
+    rb.load_state_dict(sdb)
+    rf.load_state_dict(sdf)
+    rb.train()
+    x = det_tensor((1, 3, 64, 64), 700, -2.0, 2.0)
+    outs = rf(rb(x))
+    cots = [det_tensor(tuple(o.shape), 710 + i, -1.0, 1.0) for i, o in enumerate(outs)]
+    torch.autograd.backward(outs, cots)
+    outs2, grads = O.resnet_fpn_fwd_bwd(sdb, sdf, x, 50, cots)
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)
+    for k, p in rb.named_parameters():
+        assert torch.equal(grads["backbone." + k], p.grad), k
+    for k, p in rf.named_parameters():
+        assert torch.equal(grads["neck." + k], p.grad), k
+    man["r50_fpn_small"] = {"x_seed": 700, "cot_seed0": 710, "state_seeds": [50, 51],
+                            "out_sum": [float(o.double().sum()) for o in outs],
+                            "grad_abssum_conv1": float(rb.conv1.weight.grad.double().abs().sum())}
+
+    man["torch_version"] = torch.__version__
+    with open(os.path.join(GOLD, "manifest.json"), "w") as fh:
+        json.dump(man, fh, indent=1, sort_keys=True)
+    print("golden fixtures written to", GOLD)
+    for fn in sorted(os.listdir(GOLD)):
+        print("  %-24s %8.1f KB" % (fn, os.path.getsize(os.path.join(GOLD, fn)) / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""ctypes binding of libtdn.so (the C ABI declared in include/tdn.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C torch_detection_amd/csrc``.
+There is no fallback: if the shared object is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime first so libtdn binds to the same libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtdn.so")
+
+TDN_BF16 = 0
+ADD_NONE, ADD_SAME, ADD_UP2X, ADD_SUMPOOL2 = 0, 1, 2, 3
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_float = ctypes.c_float
+
+
+class Epilogue(ctypes.Structure):
+    """Mirror of ``tdn_epilogue`` (include/tdn.h)."""
+    _fields_ = [
+        ("scale", c_void_p),
+        ("shift", c_void_p),
+        ("addend", c_void_p),
+        ("addend_mode", ctypes.c_int32),
+        ("addend_h", ctypes.c_int32),
+        ("addend_w", ctypes.c_int32),
+        ("relu", ctypes.c_int32),
+        ("mask_src", c_void_p),
+        ("out_f32", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+_EP = ctypes.POINTER(Epilogue)
+
+# name -> (restype, argtypes); must list every symbol of include/tdn.h (tests/test_abi.py checks this)
+SIGNATURES = {
+    "tdn_last_error": (ctypes.c_char_p, []),
+    "tdn_version": (c_int, []),
+    "tdn_bn_fold": (c_int, [c_void_p] * 4 + [c_float, c_int] + [c_void_p] * 3 + [c_void_p]),
+    "tdn_pack_conv_weight": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "tdn_pack_stem_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "tdn_conv2d_fwd": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
+    "tdn_conv2d_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
+    "tdn_conv2d_wgrad_workspace": (c_i64, [c_int] * 8),
+    "tdn_conv2d_wgrad": (c_int, [c_void_p] * 9 + [c_float] + [c_int] * 8 + [c_void_p, c_i64, c_int, c_void_p]),
+    "tdn_stage_image": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_int,
+                                c_void_p]),
+    "tdn_stem_conv_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [_EP, c_int, c_void_p]),
+    "tdn_stem_conv_wgrad_workspace": (c_i64, [c_int] * 4),
+    "tdn_stem_conv_wgrad": (c_int, [c_void_p] * 9 + [c_float] + [c_int] * 4 + [c_void_p, c_i64, c_int, c_void_p]),
+    "tdn_maxpool3x3s2_fwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "tdn_maxpool3x3s2_bwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "tdn_subsample2_fwd": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
+    "tdn_subsample2_bwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "tdn_add_relu_mask": (c_int, [c_void_p] * 4 + [c_i64, c_int, c_void_p]),
+    "tdn_nchw_f32_to_nhwc": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_int, c_void_p]),
+    "tdn_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "tdn_anchor_grid": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tdn_bbox_iou_pairwise": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "tdn_nms_workspace": (c_i64, [c_int]),
+    "tdn_nms": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
+                        c_void_p]),
+    "tdn_conv2d_plan": (c_int, [c_int] * 9 + [ctypes.POINTER(ctypes.c_int32)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libtdn.so (once) and attach prototypes. Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "torch_detection_amd: native library %s is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C torch_detection_amd/csrc`. "
+            "There is no CPU / eager fallback for this path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().tdn_last_error()
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    """Raw hipStream_t of PyTorch's current stream (kernels are enqueued there)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,258 @@
+// Box ops: anchor grid, pairwise IoU, greedy NMS.  HBM / latency-bound integer-index kernels.
+//
+// The reference has no implementation (core/__init__.py is empty); semantics are SURVEY.md Appendix B,
+// consistent with the conventions the reference does pin: inclusive "+1" pixel boxes
+// (datasets/utils/bbox.py:39,375-377), xyxy float32, x-fastest grid enumeration
+// (datasets/dataset_transforms.py:120-131).  Arithmetic is strict IEEE fp32 in the oracle's operation
+// order (this file is compiled with -ffp-contract=off; divisions are __fdiv_rn) so that results are
+// bit-identical to oracle/box_ref.c.
+#include "common.h"
+
+// ---- anchor grid -----------------------------------------------------------------------------------
+__global__ void anchor_grid_kernel(const float* __restrict__ base, int A, int featH, int featW, int stride,
+                                   int valid_h, int valid_w, float* __restrict__ anchors, uint8_t* valid) {
+  const int total = featH * featW * A;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int a = i % A;
+    const int cell = i / A;
+    const int x = cell % featW, y = cell / featW;
+    const float sx = (float)(x * stride), sy = (float)(y * stride);
+    const f32x4_t b = *(const f32x4_t*)(base + a * 4);
+    f32x4_t o;
+    o[0] = b[0] + sx;
+    o[1] = b[1] + sy;
+    o[2] = b[2] + sx;
+    o[3] = b[3] + sy;
+    *(f32x4_t*)(anchors + (int64_t)i * 4) = o;
+    if (valid) valid[i] = (x < valid_w && y < valid_h) ? 1 : 0;
+  }
+}
+
+extern "C" int tdn_anchor_grid(const float* base_anchors, int A, int featH, int featW, int stride, int valid_h,
+                               int valid_w, float* anchors, uint8_t* valid, void* stream) {
+  TDN_CHECK(base_anchors && anchors, "tdn_anchor_grid: NULL pointer");
+  TDN_CHECK(A > 0 && featH >= 0 && featW >= 0 && stride > 0, "tdn_anchor_grid: bad shape");
+  const int64_t total = (int64_t)featH * featW * A;
+  TDN_CHECK(total < (1ll << 30), "tdn_anchor_grid: too many anchors");
+  if (total == 0) return 0;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(anchor_grid_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, base_anchors, A, featH,
+                     featW, stride, valid_h, valid_w, anchors, valid);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- IoU -------------------------------------------------------------------------------------------
+__device__ __forceinline__ float box_area(const f32x4_t b) {
+  return __fmul_rn(__fadd_rn(__fsub_rn(b[2], b[0]), 1.0f), __fadd_rn(__fsub_rn(b[3], b[1]), 1.0f));
+}
+
+__device__ __forceinline__ float box_iou(const f32x4_t a, const float area_a, const f32x4_t b) {
+  const float ltx = fmaxf(a[0], b[0]), lty = fmaxf(a[1], b[1]);
+  const float rbx = fminf(a[2], b[2]), rby = fminf(a[3], b[3]);
+  const float w = fmaxf(__fadd_rn(__fsub_rn(rbx, ltx), 1.0f), 0.0f);
+  const float h = fmaxf(__fadd_rn(__fsub_rn(rby, lty), 1.0f), 0.0f);
+  const float inter = __fmul_rn(w, h);
+  const float area_b = box_area(b);
+  const float uni = __fsub_rn(__fadd_rn(area_a, area_b), inter);
+  return __fdiv_rn(inter, uni);
+}
+
+__global__ void iou_pairwise_kernel(const float* __restrict__ a, int N, const float* __restrict__ b, int M,
+                                    float* __restrict__ out) {
+  const int M4 = (M + 3) >> 2;
+  const int64_t total = (int64_t)N * M4;
+  const bool vec_ok = (M & 3) == 0;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / M4);
+    const int j0 = (int)(t - (int64_t)i * M4) * 4;
+    const f32x4_t ba = *(const f32x4_t*)(a + (int64_t)i * 4);
+    const float area_a = box_area(ba);
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      r[e] = (j < M) ? box_iou(ba, area_a, *(const f32x4_t*)(b + (int64_t)j * 4)) : 0.f;
+    }
+    float* o = out + (int64_t)i * M + j0;
+    if (vec_ok) {
+      *(f32x4_t*)o = (f32x4_t){r[0], r[1], r[2], r[3]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (j0 + e < M) o[e] = r[e];
+    }
+  }
+}
+
+extern "C" int tdn_bbox_iou_pairwise(const float* a, int N, const float* b, int M, float* iou, void* stream) {
+  TDN_CHECK(N >= 0 && M >= 0, "tdn_bbox_iou_pairwise: negative size");
+  if (N == 0 || M == 0) return 0;
+  TDN_CHECK(a && b && iou, "tdn_bbox_iou_pairwise: NULL pointer");
+  const int64_t total = (int64_t)N * ((M + 3) / 4);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(iou_pairwise_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a, N, b, M, iou);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- NMS -------------------------------------------------------------------------------------------
+// (1) rank[i] = #{ j : s[j] > s[i]  or  (s[j] == s[i] and j < i) }  -> stable descending order.
+__global__ void nms_rank_kernel(const float* __restrict__ scores, int N, int jchunk, int* rank) {
+  __shared__ float sj[1024];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float si = (i < N) ? scores[i] : 0.f;
+  const int jb = blockIdx.y * jchunk, je = min(N, jb + jchunk);
+  int cnt = 0;
+  for (int base = jb; base < je; base += 1024) {
+    const int n = min(1024, je - base);
+    for (int k = threadIdx.x; k < n; k += blockDim.x) sj[k] = scores[base + k];
+    __syncthreads();
+    if (i < N) {
+      for (int k = 0; k < n; ++k) {
+        const float s = sj[k];
+        const int j = base + k;
+        cnt += (s > si || (s == si && j < i)) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+  }
+  if (i < N && cnt) atomicAdd(&rank[i], cnt);
+}
+
+__global__ void nms_scatter_kernel(const float* __restrict__ boxes, const int* __restrict__ rank, int N, int* order,
+                                   float* sboxes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int r = rank[i];
+  order[r] = i;
+  *(f32x4_t*)(sboxes + (int64_t)r * 4) = *(const f32x4_t*)(boxes + (int64_t)i * 4);
+}
+
+// (2) 64-bit suppression words: mask[i][cb] bit b  <=>  j = cb*64+b > i  and  iou(i, j) > thr   (sorted order).
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ sboxes, int N, float thr, int nblk,
+                                                      unsigned long long* __restrict__ mask) {
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  __shared__ f32x4_t cbox[64];
+  const int t = threadIdx.x;
+  const int jc = cb * 64 + t;
+  cbox[t] = (jc < N) ? *(const f32x4_t*)(sboxes + (int64_t)jc * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const int i = rb * 64 + t;
+  if (i >= N) return;
+  const f32x4_t bi = *(const f32x4_t*)(sboxes + (int64_t)i * 4);
+  const float area_i = box_area(bi);
+  unsigned long long word = 0ull;
+  const int ncol = min(64, N - cb * 64);
+  for (int b = 0; b < ncol; ++b) {
+    const int j = cb * 64 + b;
+    if (j > i && box_iou(bi, area_i, cbox[b]) > thr) word |= 1ull << b;
+  }
+  mask[(int64_t)i * nblk + cb] = word;
+}
+
+// (3) serial keep scan by ONE wave: 64-box chunks; within a chunk the diagonal words are resolved with
+//     readlane + bit ops, then the kept rows are OR-ed into the running removal bitmap (lane = word).
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                      const int* __restrict__ order, int N, int nblk,
+                                                      uint8_t* keep, int64_t* kept_idx, int* num_kept) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // [nblk] removal bitmap
+  const int lane = threadIdx.x;
+  for (int w = lane; w < nblk; w += 64) remv[w] = 0ull;
+  __syncthreads();
+  int cnt = 0;
+  for (int c = 0; c < nblk; ++c) {
+    const int i = c * 64 + lane;
+    const unsigned long long diag = (i < N) ? mask[(int64_t)i * nblk + c] : 0ull;
+    const int nvalid = min(64, N - c * 64);
+    unsigned long long alive = ~remv[c];
+    if (nvalid < 64) alive &= (1ull << nvalid) - 1ull;
+    unsigned long long keepbits = 0ull;
+    const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+    while (alive) {
+      const int b = __builtin_ctzll(alive);
+      keepbits |= 1ull << b;
+      alive &= ~(1ull << b);
+      const unsigned lo = __builtin_amdgcn_readlane(dlo, b), hi = __builtin_amdgcn_readlane(dhi, b);
+      alive &= ~(((unsigned long long)hi << 32) | lo);
+    }
+    // outputs for this chunk
+    if (i < N) {
+      const bool k = (keepbits >> lane) & 1ull;
+      const int oi = order[i];
+      keep[oi] = k ? 1 : 0;
+      if (k) {
+        const int pos = cnt + __builtin_popcountll(keepbits & ((1ull << lane) - 1ull));
+        kept_idx[pos] = (int64_t)oi;
+      }
+    }
+    cnt += __builtin_popcountll(keepbits);
+    // OR kept rows into remv for the remaining words; lane handles words c+1+lane, +64, ...
+    for (int w = c + 1 + lane; w < nblk; w += 64) {
+      unsigned long long acc = 0ull;
+      unsigned long long kb = keepbits;
+      while (kb) {
+        // up to 4 independent row loads in flight
+        int b0 = __builtin_ctzll(kb); kb &= kb - 1;
+        unsigned long long v0 = mask[(int64_t)(c * 64 + b0) * nblk + w], v1 = 0, v2 = 0, v3 = 0;
+        if (kb) { int b1 = __builtin_ctzll(kb); kb &= kb - 1; v1 = mask[(int64_t)(c * 64 + b1) * nblk + w]; }
+        if (kb) { int b2 = __builtin_ctzll(kb); kb &= kb - 1; v2 = mask[(int64_t)(c * 64 + b2) * nblk + w]; }
+        if (kb) { int b3 = __builtin_ctzll(kb); kb &= kb - 1; v3 = mask[(int64_t)(c * 64 + b3) * nblk + w]; }
+        acc |= (v0 | v1) | (v2 | v3);
+      }
+      remv[w] |= acc;
+    }
+    __syncthreads();  // single wave: orders this chunk's remv writes before the next chunk's read
+  }
+  for (int k = cnt + lane; k < N; k += 64) kept_idx[k] = -1;
+  if (lane == 0) *num_kept = cnt;
+}
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~255ll; }
+
+extern "C" int64_t tdn_nms_workspace(int N) {
+  if (N <= 0) return 256;
+  const int64_t nblk = (N + 63) / 64;
+  return align256((int64_t)N * 4) * 2 + align256((int64_t)N * 16) + align256((int64_t)N * nblk * 8) + 256;
+}
+
+extern "C" int tdn_nms(const float* boxes, const float* scores, int N, float iou_thr, uint8_t* keep,
+                       int64_t* kept_idx, int32_t* num_kept, void* workspace, int64_t workspace_bytes,
+                       void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  TDN_CHECK(N >= 0 && N <= 64 * 8000, "tdn_nms: N=%d out of range (0..512000)", N);
+  TDN_CHECK(num_kept != nullptr, "tdn_nms: NULL num_kept");
+  if (N == 0) {
+    hipMemsetAsync(num_kept, 0, sizeof(int32_t), st);
+    return 0;
+  }
+  TDN_CHECK(boxes && scores && keep && kept_idx && workspace, "tdn_nms: NULL pointer");
+  TDN_CHECK(workspace_bytes >= tdn_nms_workspace(N), "tdn_nms: workspace too small");
+  TDN_CHECK(((uintptr_t)workspace & 255) == 0, "tdn_nms: workspace must be 256-byte aligned");
+  const int nblk = (N + 63) / 64;
+  char* ws = (char*)workspace;
+  int* rank = (int*)ws; ws += align256((int64_t)N * 4);
+  int* order = (int*)ws; ws += align256((int64_t)N * 4);
+  float* sboxes = (float*)ws; ws += align256((int64_t)N * 16);
+  unsigned long long* mask = (unsigned long long*)ws;
+  hipMemsetAsync(rank, 0, (size_t)N * 4, st);
+  const int nb = (N + 255) / 256;
+  int jsplit = 1024 / nb;  // aim for ~1024 blocks
+  if (jsplit < 1) jsplit = 1;
+  if (jsplit > (N + 1023) / 1024) jsplit = (N + 1023) / 1024;
+  const int jchunk = ((N + jsplit - 1) / jsplit + 1023) / 1024 * 1024;
+  jsplit = (N + jchunk - 1) / jchunk;
+  hipLaunchKernelGGL(nms_rank_kernel, dim3(nb, jsplit), dim3(256), 0, st, scores, N, jchunk, rank);
+  TDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nms_scatter_kernel, dim3(nb), dim3(256), 0, st, boxes, rank, N, order, sboxes);
+  TDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, st, sboxes, N, iou_thr, nblk, mask);
+  TDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)nblk * 8, st, mask, order, N, nblk, keep, kept_idx,
+                     num_kept);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}

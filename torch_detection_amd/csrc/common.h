@@ -1,0 +1,68 @@
+// Shared device/host helpers for libtdn (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/tdn.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+#define TDN_LDS __attribute__((address_space(3)))
+#define TDN_GLOBAL __attribute__((address_space(1)))
+
+// ---- error plumbing -------------------------------------------------------------------
+void tdn_set_error(const char* fmt, ...);
+#define TDN_CHECK(cond, ...)            \
+  do {                                  \
+    if (!(cond)) {                      \
+      tdn_set_error(__VA_ARGS__);       \
+      return -1;                        \
+    }                                   \
+  } while (0)
+#define TDN_LAUNCH_CHECK()                                              \
+  do {                                                                  \
+    hipError_t e_ = hipGetLastError();                                  \
+    if (e_ != hipSuccess) {                                             \
+      tdn_set_error("HIP launch failed at %s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return -2;                                                        \
+    }                                                                   \
+  } while (0)
+
+// ---- small device helpers -------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }
+
+// 16-byte async global -> LDS copy. LDS destination = wave-uniform `lds_base` + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
+  __builtin_amdgcn_global_load_lds((const TDN_GLOBAL void*)gsrc, (TDN_LDS void*)lds_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8_t lds_read_b128(const void* p) {
+  return *(const TDN_LDS bf16x8_t*)((const TDN_LDS char*)p);
+}
+
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p addresses row q / cols 4p..4p+3 of a 4x16 block of
+// 16-bit elements; lane i receives column i (rows 0..3 in elements 0..3).
+__device__ __forceinline__ s16x4_t lds_read_tr16(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((TDN_LDS s16x4_t*)(p));
+}
+
+// 256 zero bytes: LDS-DMA source for padding / out-of-range rows (one copy per translation unit)
+static __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+__host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// XCD-aware bijective remap: blocks b, b+8, b+16.. share an XCD (observed round-robin placement,
+// speed only) -> give each XCD a contiguous chunk of tile ids so neighbours share L2 lines.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

@@ -1,0 +1,425 @@
+// Implicit-GEMM convolution on MFMA (gfx950): forward and input-gradient of the ResNet/FPN convs.
+//
+// Replaces nn.Conv2d.forward (+ folded eval BatchNorm2d, residual add, ReLU) as called from
+// models/backbone/resnet.py:42-59,97-119,253-258 and models/necks/fpn.py:92-108, and its autograd
+// input gradient.  GEMM view:  D[n][m] = sum_k W[n][k] * X[m][k]
+//   m = output pixel (N*Ho*Wo),  n = output channel,  k = (tap, input channel)
+// X rows are gathered on the fly from the NHWC activation (one contiguous BK-channel run per tap),
+// W rows are the K-major packed weights.  Both tiles go global -> LDS with 16-byte LDS-DMA
+// (global_load_lds_dwordx4), XOR-swizzled on the *source* address so that the ds_read_b128 fragment
+// reads are bank-conflict free; the accumulator is kept as D[channel][pixel] so each lane owns 4
+// consecutive channels of one pixel (8-byte NHWC stores, float4 scale/shift loads).
+//
+// A "class" is a sub-lattice of output pixels sharing one tap list: forward and stride-1 dgrad have one
+// class; stride-2 dgrad has four output-parity classes (gather form, no atomics, no zero-insertion).
+#include "common.h"
+
+struct GemmClass {
+  int Ha, Wa, M;     // rows m -> (img, a, b) over an Ha x Wa lattice; M = N*Ha*Wa
+  int oh0, ow0;      // output pixel = (a*so + oh0, b*so + ow0)
+  int ntaps;
+  int taps[9];       // (dh+64) | (dw+64)<<8 | widx<<16 ; input pixel = (a*sa + dh, b*sa + dw)
+};
+
+struct GemmParams {
+  const bf16_t* in;
+  const bf16_t* wt;
+  bf16_t* out;
+  const float* scale;
+  const float* shift;
+  const bf16_t* addend;
+  const bf16_t* mask;
+  int Hin, Win, Cpix, Ktap, wt_row;
+  int Hout, Wout, Cout;
+  int sa, so;
+  int addend_mode, addend_h, addend_w, relu, out_f32;
+  int tiles_n, nwg_pad;
+  int ncls;
+  GemmClass cls[4];
+};
+
+
+template <int BK>
+__device__ __forceinline__ int swz_f(int row) {
+  if constexpr (BK == 64) return (row >> 1) & 7;
+  else return (4 - ((row >> 2) & 3)) & 3;
+}
+
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWB = BK * 2;
+  constexpr int CH = BK / 8;
+  constexpr int RPI = 64 / CH;
+  constexpr int A_IT = BM / (RPI * 4);
+  constexpr int B_IT = BN / (RPI * 4);
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
+  constexpr int KSUB = BK / 32;
+  static_assert(A_IT >= 1 && B_IT >= 1 && FM >= 1 && FN >= 1, "tile too small");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const GemmClass& c = p.cls[blockIdx.y];
+
+  const int bid = blockIdx.x;
+  const int tile = (bid & 7) * (p.nwg_pad >> 3) + (bid >> 3);
+  const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM;
+  if (m0 >= c.M) return;
+  const int n0 = tile_n * BN;
+
+  // ---- loader thread constants ----
+  const int lrow = lane / CH, lchunk = lane % CH;
+  const int ld_row = wave * RPI + lrow;                     // + it*RPI*4
+  const int src_chunk_el = (lchunk ^ swz_f<BK>(ld_row)) * 8;  // element offset of the 16B chunk this lane fetches
+  const int HaWa = c.Ha * c.Wa;
+  int a_pix[A_IT], a_h[A_IT], a_w[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int m = m0 + it * (RPI * 4) + ld_row;
+    if (m < c.M) {
+      const int img = m / HaWa;
+      const int rem = m - img * HaWa;
+      const int a = rem / c.Wa;
+      const int b = rem - a * c.Wa;
+      a_h[it] = a * p.sa;
+      a_w[it] = b * p.sa;
+      a_pix[it] = (img * p.Hin + a_h[it]) * p.Win + a_w[it];
+    } else {
+      a_h[it] = -(1 << 24);
+      a_w[it] = 0;
+      a_pix[it] = 0;
+    }
+  }
+  const bf16_t* b_src[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int n = n0 + it * (RPI * 4) + ld_row;
+    b_src[it] = p.wt + (int64_t)n * p.wt_row + src_chunk_el;
+  }
+  const bf16_t* zero_src = (const bf16_t*)g_zero_page + src_chunk_el;
+
+  const int kchunks = p.Ktap / BK;
+  const int T = c.ntaps * kchunks;
+
+  auto stage_load = [&](int t, int s) {
+    const int tap_i = t / kchunks;
+    const int kc = t - tap_i * kchunks;
+    const int tp = c.taps[tap_i];
+    const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
+    char* sA = smem + s * STAGE + wave * (RPI * ROWB);
+    char* sB = sA + A_BYTES;
+    const int koff_a = kc * BK;
+    const int dpix = dh * p.Win + dw;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int h = a_h[it] + dh, w = a_w[it] + dw;
+      const bool ok = ((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win);
+      const bf16_t* src = ok ? p.in + ((int64_t)(a_pix[it] + dpix) * p.Cpix + koff_a + src_chunk_el) : zero_src;
+      glds16(src, sA + it * (RPI * 4 * ROWB));
+    }
+    const int koff_b = widx * p.Ktap + kc * BK;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) glds16(b_src[it] + koff_b, sB + it * (RPI * 4 * ROWB));
+  };
+
+  // ---- fragment reader constants ----
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int f_rd = swz_f<BK>(fr);
+  int rd_off[KSUB];
+#pragma unroll
+  for (int kk = 0; kk < KSUB; ++kk) rd_off[kk] = fr * ROWB + (((kk * 4 + fq) ^ f_rd) * 16);
+
+  f32x4_t acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (T > 0) {
+    stage_load(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) stage_load(t + 1, (t + 1) & 1);
+      const char* sA = smem + (t & 1) * STAGE + (wm * WTM) * ROWB;
+      const char* sB = smem + (t & 1) * STAGE + A_BYTES + (wn * WTN) * ROWB;
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk) {
+        bf16x8_t wf[FN], xf[FM];
+#pragma unroll
+        for (int i = 0; i < FN; ++i) wf[i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[kk]);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) xf[j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[kk]);
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: lane owns channels ch..ch+3 of pixel m for each (i, j) fragment ----
+  const int ch_base = n0 + wn * WTN + fq * 4;
+  f32x4_t sc[FN], sh[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    sc[i] = p.scale ? *(const f32x4_t*)(p.scale + ch_base + i * 16) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+    sh[i] = p.shift ? *(const f32x4_t*)(p.shift + ch_base + i * 16) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = m0 + wm * WTM + j * 16 + fr;
+    if (m >= c.M) continue;
+    const int img = m / HaWa;
+    const int rem = m - img * HaWa;
+    const int a = rem / c.Wa;
+    const int b = rem - a * c.Wa;
+    const int oh = a * p.so + c.oh0, ow = b * p.so + c.ow0;
+    const int64_t opix = ((int64_t)img * p.Hout + oh) * p.Wout + ow;
+    int64_t apix = opix;
+    if (p.addend_mode == TDN_ADD_UP2X)
+      apix = ((int64_t)img * p.addend_h + (oh >> 1)) * p.addend_w + (ow >> 1);
+    else if (p.addend_mode == TDN_ADD_SUMPOOL2)
+      apix = ((int64_t)img * p.addend_h + 2 * oh) * p.addend_w + 2 * ow;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int ch = ch_base + i * 16;
+      f32x4_t v = acc[i][j] * sc[i] + sh[i];
+      if (p.addend_mode != TDN_ADD_NONE) {
+        const bf16_t* ap = p.addend + apix * p.Cout + ch;
+        bf16x4_t r = *(const bf16x4_t*)ap;
+        if (p.addend_mode == TDN_ADD_SUMPOOL2) {
+          // sum in a fixed order: (0,0) + (0,1) + (1,0) + (1,1)
+          bf16x4_t r1 = *(const bf16x4_t*)(ap + p.Cout);
+          bf16x4_t r2 = *(const bf16x4_t*)(ap + (int64_t)p.addend_w * p.Cout);
+          bf16x4_t r3 = *(const bf16x4_t*)(ap + (int64_t)(p.addend_w + 1) * p.Cout);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] += (((float)r[e] + (float)r1[e]) + (float)r2[e]) + (float)r3[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+        }
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.mask) {
+        bf16x4_t mk = *(const bf16x4_t*)(p.mask + opix * p.Cout + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((float)mk[e] > 0.f) ? v[e] : 0.f;
+      }
+      if (p.out_f32) {
+        *(f32x4_t*)((float*)p.out + opix * p.Cout + ch) = v;
+      } else {
+        bf16x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+        *(bf16x4_t*)(p.out + opix * p.Cout + ch) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline int pack_tap(int dh, int dw, int widx) { return (dh + 64) | ((dw + 64) << 8) | (widx << 16); }
+
+struct TileChoice { int bm, bn; };
+
+static TileChoice choose_tile(int maxM, int ngemm) {
+  TileChoice t;
+  t.bn = (ngemm % 128 == 0) ? 128 : 64;
+  t.bm = 128;
+  const long tiles = (long)ceil_div(maxM, 128) * (ngemm / t.bn);
+  if (tiles < 384) t.bm = 64;
+  const char* env = getenv("TDN_TILE");
+  if (env) {
+    int bm = 0, bn = 0;
+    if (sscanf(env, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) &&
+        ngemm % bn == 0) {
+      t.bm = bm;
+      t.bn = bn;
+    }
+  }
+  return t;
+}
+
+template <int BM, int BN, int BK>
+static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
+  p.tiles_n = p.Cout / BN;
+  const int ntiles = ceil_div(maxM, BM) * p.tiles_n;
+  p.nwg_pad = (ntiles + 7) & ~7;
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, BK>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(p.nwg_pad, p.ncls, 1), block(256, 1, 1);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK>), grid, block, lds, stream, p);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
+  if (maxM <= 0) return 0;
+  const TileChoice t = choose_tile(maxM, p.Cout);
+  if (t.bm == 128 && t.bn == 128) return launch_gemm<128, 128, 64>(p, maxM, stream);
+  if (t.bm == 128 && t.bn == 64) return launch_gemm<128, 64, 64>(p, maxM, stream);
+  if (t.bm == 64 && t.bn == 128) return launch_gemm<64, 128, 64>(p, maxM, stream);
+  return launch_gemm<64, 64, 64>(p, maxM, stream);
+}
+
+static int fill_epilogue(GemmParams& p, const tdn_epilogue* ep, int Hout, int Wout) {
+  p.scale = nullptr; p.shift = nullptr; p.addend = nullptr; p.mask = nullptr;
+  p.addend_mode = TDN_ADD_NONE; p.addend_h = 0; p.addend_w = 0; p.relu = 0; p.out_f32 = 0;
+  if (!ep) return 0;
+  p.out_f32 = ep->out_f32 ? 1 : 0;
+  p.scale = ep->scale;
+  p.shift = ep->shift;
+  p.relu = ep->relu;
+  p.mask = (const bf16_t*)ep->mask_src;
+  if (ep->addend_mode != TDN_ADD_NONE) {
+    TDN_CHECK(ep->addend != nullptr, "epilogue: addend_mode %d with NULL addend", ep->addend_mode);
+    p.addend = (const bf16_t*)ep->addend;
+    p.addend_mode = ep->addend_mode;
+    p.addend_h = ep->addend_h;
+    p.addend_w = ep->addend_w;
+    if (ep->addend_mode == TDN_ADD_UP2X)
+      TDN_CHECK(ep->addend_h * 2 == Hout && ep->addend_w * 2 == Wout,
+                "epilogue UP2X: addend %dx%d is not half of output %dx%d", ep->addend_h, ep->addend_w, Hout, Wout);
+    if (ep->addend_mode == TDN_ADD_SUMPOOL2)
+      TDN_CHECK(ep->addend_h == Hout * 2 && ep->addend_w == Wout * 2,
+                "epilogue SUMPOOL2: addend %dx%d is not twice the output %dx%d", ep->addend_h, ep->addend_w, Hout, Wout);
+    TDN_CHECK(ep->addend_mode >= 0 && ep->addend_mode <= 3, "epilogue: bad addend_mode %d", ep->addend_mode);
+  }
+  return 0;
+}
+
+static int check_conv_shape(int N, int H, int W, int Cin, int Cout, int k, int stride, int pad, int dtype) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported (got dtype %d)", dtype);
+  TDN_CHECK(N > 0 && H > 0 && W > 0, "bad tensor shape N=%d H=%d W=%d", N, H, W);
+  TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported (1 or 3)", k);
+  TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported (1 or 2)", stride);
+  TDN_CHECK(pad == k / 2, "pad %d not supported for k=%d (need k/2)", pad, k);
+  TDN_CHECK(Cin % 64 == 0 && Cout % 64 == 0, "channels must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
+  TDN_CHECK((int64_t)N * H * W < (1ll << 31) / 4, "tensor too large for 32-bit pixel indexing");
+  return 0;
+}
+
+static void build_fwd(GemmParams& p, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  p.Hin = H; p.Win = W; p.Cpix = Cin; p.Ktap = Cin; p.wt_row = k * k * Cin;
+  p.Hout = Ho; p.Wout = Wo; p.Cout = Cout; p.sa = stride; p.so = 1; p.ncls = 1;
+  GemmClass& c = p.cls[0];
+  c.Ha = Ho; c.Wa = Wo; c.M = N * Ho * Wo; c.oh0 = 0; c.ow0 = 0; c.ntaps = 0;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) c.taps[c.ntaps++] = pack_tap(kh - pad, kw - pad, kh * k + kw);
+}
+
+// Input gradient as a gather: dx[hi][wi] = sum over (kh,kw) with (hi+pad-kh) % s == 0 of g[(hi+pad-kh)/s] * w[kh][kw].
+static int build_dgrad(GemmParams& p, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  p.Hin = Ho; p.Win = Wo; p.Cpix = Cout; p.Ktap = Cout; p.wt_row = k * k * Cout;
+  p.Hout = H; p.Wout = W; p.Cout = Cin; p.sa = 1; p.so = stride;
+  p.ncls = stride * stride;
+  int maxM = 0;
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      GemmClass& c = p.cls[ph * stride + pw];
+      c.Ha = (H - ph + stride - 1) / stride;
+      c.Wa = (W - pw + stride - 1) / stride;
+      if (c.Ha < 0) c.Ha = 0;
+      if (c.Wa < 0) c.Wa = 0;
+      c.M = N * c.Ha * c.Wa;
+      c.oh0 = ph; c.ow0 = pw; c.ntaps = 0;
+      for (int kh = 0; kh < k; ++kh) {
+        if ((ph + pad - kh) % stride != 0) continue;
+        for (int kw = 0; kw < k; ++kw) {
+          if ((pw + pad - kw) % stride != 0) continue;
+          c.taps[c.ntaps++] = pack_tap((ph + pad - kh) / stride, (pw + pad - kw) / stride, kh * k + kw);
+        }
+      }
+      if (c.M > maxM) maxM = c.M;
+    }
+  return maxM;
+}
+
+extern "C" int tdn_conv2d_fwd(const void* x, const void* w_fwd, void* y, int N, int H, int W, int Cin,
+                              int Cout, int k, int stride, int pad, const tdn_epilogue* ep, int dtype,
+                              void* stream) {
+  if (check_conv_shape(N, H, W, Cin, Cout, k, stride, pad, dtype)) return -1;
+  TDN_CHECK(x && w_fwd && y, "tdn_conv2d_fwd: NULL tensor pointer");
+  GemmParams p;
+  build_fwd(p, N, H, W, Cin, Cout, k, stride, pad);
+  p.in = (const bf16_t*)x; p.wt = (const bf16_t*)w_fwd; p.out = (bf16_t*)y;
+  if (fill_epilogue(p, ep, p.Hout, p.Wout)) return -1;
+  return dispatch_gemm(p, p.cls[0].M, (hipStream_t)stream);
+}
+
+extern "C" int tdn_conv2d_dgrad(const void* g, const void* w_dgrad, void* dx, int N, int H, int W, int Cin,
+                                int Cout, int k, int stride, int pad, const tdn_epilogue* ep, int dtype,
+                                void* stream) {
+  if (check_conv_shape(N, H, W, Cin, Cout, k, stride, pad, dtype)) return -1;
+  TDN_CHECK(g && w_dgrad && dx, "tdn_conv2d_dgrad: NULL tensor pointer");
+  GemmParams p;
+  const int maxM = build_dgrad(p, N, H, W, Cin, Cout, k, stride, pad);
+  p.in = (const bf16_t*)g; p.wt = (const bf16_t*)w_dgrad; p.out = (bf16_t*)dx;
+  if (fill_epilogue(p, ep, p.Hout, p.Wout)) return -1;
+  return dispatch_gemm(p, maxM, (hipStream_t)stream);
+}
+
+// Stem: 7x7 s2 p3 conv on the zero-padded NHWC4 staging buffer xp[N][H+6][W+8][4]. One "tap" per kernel
+// row kh: 8 consecutive pixels x 4 channels = 32 contiguous bf16 (kw = 7 and c = 3 carry zero weights).
+extern "C" int tdn_stem_conv_fwd(const void* xp, const void* w_stem, void* y, int N, int H, int W, int Cout,
+                                 const tdn_epilogue* ep, int dtype, void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(xp && w_stem && y, "tdn_stem_conv_fwd: NULL tensor pointer");
+  TDN_CHECK(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0 && N > 0, "stem needs even H, W (got %dx%d)", H, W);
+  TDN_CHECK(Cout % 64 == 0, "stem Cout must be a multiple of 64");
+  GemmParams p;
+  const int Ho = H / 2, Wo = W / 2;
+  p.Hin = H + 6; p.Win = W + 8; p.Cpix = 4; p.Ktap = 32; p.wt_row = 7 * 32;
+  p.Hout = Ho; p.Wout = Wo; p.Cout = Cout; p.sa = 2; p.so = 1; p.ncls = 1;
+  GemmClass& c = p.cls[0];
+  c.Ha = Ho; c.Wa = Wo; c.M = N * Ho * Wo; c.oh0 = 0; c.ow0 = 0; c.ntaps = 7;
+  for (int kh = 0; kh < 7; ++kh) c.taps[kh] = pack_tap(kh, 0, kh);
+  p.in = (const bf16_t*)xp; p.wt = (const bf16_t*)w_stem; p.out = (bf16_t*)y;
+  if (fill_epilogue(p, ep, Ho, Wo)) return -1;
+  return launch_gemm<128, 64, 32>(p, c.M, (hipStream_t)stream);
+}
+
+extern "C" int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                               int32_t* out16);
+int tdn_wgrad_plan(int N, int H, int W, int Cin, int Cout, int k, int stride, int pad, int32_t* out16);
+
+extern "C" int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                               int32_t* o) {
+  if (check_conv_shape(N, H, W, Cin, Cout, k, stride, pad, TDN_BF16)) return -1;
+  TDN_CHECK(o != nullptr, "tdn_conv2d_plan: NULL output");
+  for (int i = 0; i < 16; ++i) o[i] = 0;
+  if (kind == 2) return tdn_wgrad_plan(N, H, W, Cin, Cout, k, stride, pad, o);
+  TDN_CHECK(kind == 0 || kind == 1, "tdn_conv2d_plan: bad kind %d", kind);
+  GemmParams p;
+  int maxM;
+  if (kind == 0) { build_fwd(p, N, H, W, Cin, Cout, k, stride, pad); maxM = p.cls[0].M; }
+  else maxM = build_dgrad(p, N, H, W, Cin, Cout, k, stride, pad);
+  const TileChoice t = choose_tile(maxM, p.Cout);
+  int Mtot = 0, taps_tot = 0;
+  for (int i = 0; i < p.ncls; ++i) { Mtot += p.cls[i].M; taps_tot += p.cls[i].ntaps; }
+  o[0] = Mtot; o[1] = p.Cout; o[2] = p.cls[0].ntaps * p.Ktap; o[3] = t.bm; o[4] = t.bn; o[5] = 64;
+  o[6] = (ceil_div(maxM, t.bm) * (p.Cout / t.bn) + 7) & ~7; o[7] = p.ncls; o[8] = 1; o[9] = p.ncls;
+  o[10] = p.cls[0].ntaps; o[11] = 1; o[12] = taps_tot; o[13] = p.Hout; o[14] = p.Wout; o[15] = maxM;
+  return 0;
+}

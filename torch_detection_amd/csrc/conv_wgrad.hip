@@ -1,0 +1,378 @@
+// Weight-gradient GEMM on MFMA (gfx950) + finalize (BN-affine / bias grads, split-K reduction).
+//
+// Autograd of nn.Conv2d weights / BatchNorm2d affine / conv bias for the layers built at
+// models/backbone/resnet.py:74-91,214-216 and models/necks/fpn.py:44-58 (the reference never calls
+// backward itself; the oracle is torch autograd on the CPU restatement).
+//
+//   G[co][tap][ci] = sum_m g[m][co] * x[pix(m) + tap][ci]          (m = output pixel)
+// Both operands are pixel-major (NHWC), i.e. the reduction index m is the SLOW index of both tiles, so
+// fragments are fetched with ds_read_b64_tr_b16 (hardware transpose read) from row-major LDS tiles that
+// are filled by 16-byte LDS-DMA.  D is kept as D[ci][co] so a lane owns 4 consecutive ci (float4 stores).
+// sum_m g[m][co] (dbeta / dbias) comes from one extra MFMA against a ones fragment — no extra traffic.
+// Split-K over pixels writes fp32 slabs; tdn finalize reduces them in a fixed order (deterministic).
+#include "common.h"
+
+struct WgradParams {
+  const bf16_t* x;
+  const bf16_t* g;
+  float* slab;      // [splitk][Cout][Ktot]
+  float* colsum;    // [splitk][Cout]
+  int Hin, Win, Cpix, Ktap;   // x geometry (pixel stride Cpix elements, Ktap elements consumed per tap)
+  int Ho, Wo, Cout, sa;
+  int M, Mchunk, splitk;
+  int ntaps, Ktot;
+  int tiles_co, tiles_k;     // tiles over Cout, tiles over (tap, ci)
+  int taps[9];               // (dh+64) | (dw+64)<<8
+};
+
+
+// 32-byte-chunk XOR swizzle for tr-read tiles, by row bytes.
+template <int RB>
+__device__ __forceinline__ int tr_swz(int row) {
+  if constexpr (RB >= 256) return (row & 3) | (((row >> 3) & 1) << 2);
+  else if constexpr (RB == 128) return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+  else return (row >> 3) & 1;
+}
+
+template <int BMW /*co*/, int BNW /*ci*/>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKW = 64;                       // pixels per stage
+  constexpr int RBG = BMW * 2, RBX = BNW * 2;   // row bytes
+  constexpr int G_BYTES = BKW * RBG, X_BYTES = BKW * RBX, STAGE = G_BYTES + X_BYTES;
+  constexpr int RPIG = 1024 / RBG, RPIX = 1024 / RBX;   // rows per wave-instruction
+  constexpr int G_IT = BKW / (RPIG * 4) > 0 ? BKW / (RPIG * 4) : 1;
+  constexpr int X_IT = BKW / (RPIX * 4) > 0 ? BKW / (RPIX * 4) : 1;
+  constexpr bool G_PART = (RPIG * 4 > BKW), X_PART = (RPIX * 4 > BKW);  // fewer than 4 waves needed
+  constexpr int WTM = BMW / 2, WTN = BNW / 2, FM = WTM / 16, FN = WTN / 16;  // per-wave co / ci frags
+  static_assert(FM >= 1 && FN >= 1, "tile too small");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int tile = blockIdx.x;
+  const int tile_co = tile % p.tiles_co, tile_k = tile / p.tiles_co;
+  const int co0 = tile_co * BMW;
+  const int kt_per_tap = p.Ktap / BNW;
+  const int tap_i = tile_k / kt_per_tap;
+  const int ci0 = (tile_k - tap_i * kt_per_tap) * BNW;
+  const int tp = p.taps[tap_i];
+  const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64;
+  const int split = blockIdx.y;
+  const int m_begin = split * p.Mchunk;
+  const int m_end = min(p.M, m_begin + p.Mchunk);
+
+  // ---- loader constants ----
+  constexpr int CPRG = RBG / 16, CPRX = RBX / 16;  // 16B chunks per row
+  const int g_lrow = lane / CPRG, g_pc = lane % CPRG;
+  const int x_lrow = lane / CPRX, x_pc = lane % CPRX;
+  const int g_row0 = wave * RPIG + g_lrow;   // + it*RPIG*4
+  const int x_row0 = wave * RPIX + x_lrow;
+  const int g_src_el = ((((g_pc >> 1) ^ tr_swz<RBG>(g_row0)) << 1) | (g_pc & 1)) * 8;
+  const int x_src_el = ((((x_pc >> 1) ^ tr_swz<RBX>(x_row0)) << 1) | (x_pc & 1)) * 8;
+  const bf16_t* zero = (const bf16_t*)g_zero_page;
+
+  // pixel decode state for this thread's x rows (advanced incrementally by BKW per stage)
+  int xa[X_IT], xb[X_IT], ximg[X_IT];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int it = 0; it < X_IT; ++it) {
+    const int m = m_begin + it * (RPIX * 4) + x_row0;
+    const int img = m / HoWo;
+    const int rem = m - img * HoWo;
+    ximg[it] = img;
+    xa[it] = rem / p.Wo;
+    xb[it] = rem - xa[it] * p.Wo;
+  }
+
+  auto stage_load = [&](int mt, int s) {
+    char* sG = smem + s * STAGE;
+    char* sX = sG + G_BYTES;
+    if (!G_PART || g_row0 < BKW) {
+#pragma unroll
+      for (int it = 0; it < G_IT; ++it) {
+        const int r = it * (RPIG * 4) + g_row0;
+        const int m = mt + r;
+        const bf16_t* src = (m < m_end) ? p.g + ((int64_t)m * p.Cout + co0 + g_src_el) : zero + (g_src_el & 127);
+        glds16(src, sG + (it * (RPIG * 4) + wave * RPIG) * RBG);
+      }
+    }
+    if (!X_PART || x_row0 < BKW) {
+#pragma unroll
+      for (int it = 0; it < X_IT; ++it) {
+        const int r = it * (RPIX * 4) + x_row0;
+        const int m = mt + r;
+        const int h = xa[it] * p.sa + dh, w = xb[it] * p.sa + dw;
+        const bool ok = (m < m_end) && ((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win);
+        const bf16_t* src = ok ? p.x + (((int64_t)(ximg[it] * p.Hin + h) * p.Win + w) * p.Cpix + ci0 + x_src_el)
+                               : zero + (x_src_el & 127);
+        glds16(src, sX + (it * (RPIX * 4) + wave * RPIX) * RBX);
+        // advance to the next stage's pixel
+        xb[it] += BKW;
+        while (xb[it] >= p.Wo) { xb[it] -= p.Wo; xa[it] += 1; }
+        while (xa[it] >= p.Ho) { xa[it] -= p.Ho; ximg[it] += 1; }
+      }
+    }
+  };
+
+  // ---- fragment reader constants (ds_read_b64_tr_b16) ----
+  const int wm = wave >> 1, wn = wave & 1;
+  const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int rrow = 8 * grp + q;                 // + kk*32 + 4*half
+  const int fG = tr_swz<RBG>(rrow), fX = tr_swz<RBX>(rrow);
+  int g_off[FM], x_off[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int c5 = (wm * WTM + i * 16) >> 4;    // 32-byte chunk index of this fragment's 16 channels
+    g_off[i] = rrow * RBG + ((c5 ^ fG) << 5) + pp * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int c5 = (wn * WTN + j * 16) >> 4;
+    x_off[j] = rrow * RBX + ((c5 ^ fX) << 5) + pp * 8;
+  }
+
+  f32x4_t acc[FM][FN];
+  f32x4_t acc1[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    acc1[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_colsum = (tile_k == 0) && (wn == 0);
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+
+  const int T = (m_end > m_begin) ? ceil_div(m_end - m_begin, BKW) : 0;
+  if (T > 0) {
+    stage_load(m_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) stage_load(m_begin + (t + 1) * BKW, (t + 1) & 1);
+      const char* sG = smem + (t & 1) * STAGE;
+      const char* sX = sG + G_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8_t gf[FM], xf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const s16x4_t lo = lds_read_tr16(sG + g_off[i] + kk * 32 * RBG);
+          const s16x4_t hi = lds_read_tr16(sG + g_off[i] + (kk * 32 + 4) * RBG);
+          s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          gf[i] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const s16x4_t lo = lds_read_tr16(sX + x_off[j] + kk * 32 * RBX);
+          const s16x4_t hi = lds_read_tr16(sX + x_off[j] + (kk * 32 + 4) * RBX);
+          s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          xf[j] = __builtin_bit_cast(bf16x8_t, v);
+        }
+        // D[row = ci][col = co] += sum_m X[m][ci] * G[m][co]
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], gf[i], acc[i][j], 0, 0, 0);
+        if (do_colsum) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+            acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, gf[i], acc1[i], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // ---- store: lane holds ci = ci_base + 4*grp .. +3 for co = co_base + (lane&15) ----
+  const int fr = lane & 15;
+  float* slab = p.slab + (int64_t)split * p.Cout * p.Ktot;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int co = co0 + wm * WTM + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int kidx = tap_i * p.Ktap + ci0 + wn * WTN + j * 16 + grp * 4;
+      *(f32x4_t*)(slab + (int64_t)co * p.Ktot + kidx) = acc[i][j];
+    }
+    if (do_colsum && grp == 0) p.colsum[(int64_t)split * p.Cout + co] = acc1[i][0];
+  }
+}
+
+// One block per output channel: reduce split-K slabs in order, scale, and produce affine grads.
+//   map_mode 0: dw index = co*Ktot + k  ([Cout][kh][kw][Cin] = channels_last view of the OIHW grad)
+//   map_mode 1: stem, k = (kh*8 + kw)*4 + c  ->  dw[co][c][kh][kw] contiguous (pads dropped)
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ slab,
+                                                             const float* __restrict__ colsum, int splitk,
+                                                             int Cout, int Ktot, const bf16_t* __restrict__ w_fwd,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* dw,
+                                                             float* dgamma, float* dbeta, float beta,
+                                                             int map_mode) {
+  const int co = blockIdx.x;
+  const float sc = scale ? scale[co] : 1.f;
+  float dot = 0.f;
+  for (int k = threadIdx.x; k < Ktot; k += 256) {
+    float s = 0.f;
+    for (int sp = 0; sp < splitk; ++sp) s += slab[((int64_t)sp * Cout + co) * Ktot + k];
+    dot += (float)w_fwd[(int64_t)co * Ktot + k] * s;
+    int64_t oidx;
+    if (map_mode == 0) {
+      oidx = (int64_t)co * Ktot + k;
+    } else {
+      const int c = k & 3, kw = (k >> 2) & 7, kh = k >> 5;
+      if (c == 3 || kw == 7) continue;
+      oidx = (int64_t)co * 147 + c * 49 + kh * 7 + kw;
+    }
+    const float v = sc * s;
+    dw[oidx] = (beta != 0.f) ? beta * dw[oidx] + v : v;
+  }
+  // block reduce dot
+  __shared__ float red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float d = (red[0] + red[1]) + (red[2] + red[3]);
+    float cs = 0.f;
+    for (int sp = 0; sp < splitk; ++sp) cs += colsum[(int64_t)sp * Cout + co];
+    if (dbeta) dbeta[co] = (beta != 0.f) ? beta * dbeta[co] + cs : cs;
+    if (mean && invstd && dgamma) {
+      const float dg = (d - mean[co] * cs) * invstd[co];
+      dgamma[co] = (beta != 0.f) ? beta * dgamma[co] + dg : dg;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct WgradPlan { int bmw, bnw, tiles_co, tiles_k, splitk, mchunk, M, Ktot; };
+
+static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps) {
+  WgradPlan w;
+  w.bmw = (Cout % 128 == 0) ? 128 : 64;
+  w.bnw = (Ktap % 128 == 0) ? 128 : (Ktap % 64 == 0 ? 64 : 32);
+  w.tiles_co = Cout / w.bmw;
+  w.tiles_k = ntaps * (Ktap / w.bnw);
+  w.M = M;
+  w.Ktot = ntaps * Ktap;
+  const int tiles = w.tiles_co * w.tiles_k;
+  // aim for ~1024 workgroups, at least 512 pixels of reduction each
+  int splitk = ceil_div(1024, tiles);
+  const int max_split = ceil_div(M, 512) > 0 ? ceil_div(M, 512) : 1;
+  if (splitk > max_split) splitk = max_split;
+  if (splitk > 256) splitk = 256;
+  if (splitk < 1) splitk = 1;
+  int mchunk = ceil_div(ceil_div(M, splitk), 64) * 64;
+  splitk = ceil_div(M, mchunk);
+  w.splitk = splitk;
+  w.mchunk = mchunk;
+  return w;
+}
+
+static int64_t wgrad_ws_bytes(const WgradPlan& w, int Cout) {
+  return ((int64_t)w.splitk * Cout * w.Ktot + (int64_t)w.splitk * Cout) * 4 + 256;
+}
+
+template <int BMW, int BNW>
+static int launch_wgrad(const WgradParams& p, hipStream_t stream) {
+  constexpr size_t lds = 2 * (size_t)64 * (BMW + BNW) * 2;
+  dim3 grid(p.tiles_co * p.tiles_k, p.splitk, 1), block(256, 1, 1);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW>), grid, block, lds, stream, p);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+static int run_wgrad(WgradParams& p, const WgradPlan& w, const void* w_fwd, const float* scale,
+                     const float* mean, const float* invstd, float* dw, float* dgamma, float* dbeta,
+                     float beta, void* workspace, int64_t workspace_bytes, int map_mode, hipStream_t stream) {
+  TDN_CHECK(workspace_bytes >= wgrad_ws_bytes(w, p.Cout), "wgrad workspace too small: %lld < %lld",
+            (long long)workspace_bytes, (long long)wgrad_ws_bytes(w, p.Cout));
+  TDN_CHECK(((uintptr_t)workspace & 15) == 0, "wgrad workspace must be 16-byte aligned");
+  p.slab = (float*)workspace;
+  p.colsum = p.slab + (int64_t)w.splitk * p.Cout * w.Ktot;
+  p.M = w.M; p.Mchunk = w.mchunk; p.splitk = w.splitk; p.Ktot = w.Ktot;
+  p.tiles_co = w.tiles_co; p.tiles_k = w.tiles_k;
+  int rc;
+  if (w.bmw == 128 && w.bnw == 128) rc = launch_wgrad<128, 128>(p, stream);
+  else if (w.bmw == 128 && w.bnw == 64) rc = launch_wgrad<128, 64>(p, stream);
+  else if (w.bmw == 64 && w.bnw == 128) rc = launch_wgrad<64, 128>(p, stream);
+  else if (w.bmw == 64 && w.bnw == 64) rc = launch_wgrad<64, 64>(p, stream);
+  else if (w.bmw == 64 && w.bnw == 32) rc = launch_wgrad<64, 32>(p, stream);
+  else { tdn_set_error("wgrad: no kernel for tile %dx%d", w.bmw, w.bnw); return -1; }
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(p.Cout), dim3(256), 0, stream, p.slab, p.colsum, w.splitk,
+                     p.Cout, w.Ktot, (const bf16_t*)w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, map_mode);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+static int conv_out(int H, int k, int stride, int pad) { return (H + 2 * pad - k) / stride + 1; }
+
+extern "C" int64_t tdn_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int k, int stride,
+                                               int pad) {
+  const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
+  const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, Cin, k * k);
+  return wgrad_ws_bytes(w, Cout);
+}
+
+int tdn_wgrad_plan(int N, int H, int W, int Cin, int Cout, int k, int stride, int pad, int32_t* o) {
+  const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
+  const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, Cin, k * k);
+  o[0] = Cout; o[1] = w.Ktot; o[2] = w.M; o[3] = w.bmw; o[4] = w.bnw; o[5] = 64;
+  o[6] = w.tiles_co * w.tiles_k; o[7] = w.splitk; o[8] = 1; o[9] = 1; o[10] = k * k; o[11] = w.splitk;
+  o[12] = w.mchunk; o[13] = Ho; o[14] = Wo; o[15] = w.M;
+  return 0;
+}
+
+extern "C" int tdn_conv2d_wgrad(const void* x, const void* g, const void* w_fwd, const float* scale,
+                                const float* mean, const float* invstd, float* dw, float* dgamma,
+                                float* dbeta, float beta, int N, int H, int W, int Cin, int Cout, int k,
+                                int stride, int pad, void* workspace, int64_t workspace_bytes, int dtype,
+                                void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(x && g && w_fwd && dw && workspace, "tdn_conv2d_wgrad: NULL pointer");
+  TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported", k);
+  TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported", stride);
+  TDN_CHECK(pad == k / 2, "pad %d not supported for k=%d", pad, k);
+  TDN_CHECK(Cin % 64 == 0 && Cout % 64 == 0, "channels must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
+  const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
+  const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, Cin, k * k);
+  WgradParams p;
+  p.x = (const bf16_t*)x; p.g = (const bf16_t*)g;
+  p.Hin = H; p.Win = W; p.Cpix = Cin; p.Ktap = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.sa = stride;
+  p.ntaps = k * k;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) p.taps[kh * k + kw] = (kh - pad + 64) | ((kw - pad + 64) << 8);
+  return run_wgrad(p, w, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes, 0,
+                   (hipStream_t)stream);
+}
+
+extern "C" int64_t tdn_stem_conv_wgrad_workspace(int N, int H, int W, int Cout) {
+  const WgradPlan w = plan_wgrad(N * (H / 2) * (W / 2), Cout, 32, 7);
+  return wgrad_ws_bytes(w, Cout);
+}
+
+extern "C" int tdn_stem_conv_wgrad(const void* xp, const void* g, const void* w_stem, const float* scale,
+                                   const float* mean, const float* invstd, float* dw, float* dgamma,
+                                   float* dbeta, float beta, int N, int H, int W, int Cout, void* workspace,
+                                   int64_t workspace_bytes, int dtype, void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(xp && g && w_stem && dw && workspace, "tdn_stem_conv_wgrad: NULL pointer");
+  TDN_CHECK(H % 2 == 0 && W % 2 == 0 && Cout % 64 == 0, "stem wgrad: bad shape");
+  const int Ho = H / 2, Wo = W / 2;
+  const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, 32, 7);
+  WgradParams p;
+  p.x = (const bf16_t*)xp; p.g = (const bf16_t*)g;
+  p.Hin = H + 6; p.Win = W + 8; p.Cpix = 4; p.Ktap = 32; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.sa = 2;
+  p.ntaps = 7;
+  for (int kh = 0; kh < 7; ++kh) p.taps[kh] = (kh + 64) | ((0 + 64) << 8);
+  return run_wgrad(p, w, w_stem, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes, 1,
+                   (hipStream_t)stream);
+}

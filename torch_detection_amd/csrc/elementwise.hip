@@ -1,0 +1,424 @@
+// HBM-bound helper kernels of the ResNet/FPN path: weight packing, BN folding, image staging,
+// max-pool (resnet.py:218,258), stride-2 subsample (fpn.py:116), ReLU-mask/add, layout converters.
+// All are 16-byte-per-lane streaming kernels over NHWC bf16.
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void tdn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* tdn_last_error(void) { return g_err; }
+extern "C" int tdn_version(void) { return TDN_VERSION; }
+
+static inline int grid_for(int64_t n, int block) {
+  int64_t g = (n + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- BN fold ---------------------------------------------------------------------------------
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var,
+                               float eps, int C, float* scale, float* shift, float* invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.0f / sqrtf(var[c] + eps);
+  const float s = gamma[c] * is;
+  scale[c] = s;
+  shift[c] = beta[c] - mean[c] * s;
+  invstd[c] = is;
+}
+
+extern "C" int tdn_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                           float eps, int C, float* scale, float* shift, float* invstd, void* stream) {
+  TDN_CHECK(gamma && beta && mean && var && scale && shift && invstd, "tdn_bn_fold: NULL pointer");
+  TDN_CHECK(C > 0, "tdn_bn_fold: C=%d", C);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     mean, var, eps, C, scale, shift, invstd);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- weight packing --------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int Cout,
+                                   int Cin, int kh, int kw, const float* scale, bf16_t* w_fwd, bf16_t* w_dgrad) {
+  const int64_t total = (int64_t)Cout * Cin * kh * kw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // i enumerates the fwd layout [co][h][w][ci]
+    const int ci = (int)(i % Cin);
+    int64_t r = i / Cin;
+    const int x = (int)(r % kw);
+    r /= kw;
+    const int y = (int)(r % kh);
+    const int co = (int)(r / kh);
+    const float v = w[co * s_o + ci * s_i + y * s_h + x * s_w];
+    const bf16_t vb = (bf16_t)v;
+    w_fwd[i] = vb;
+    if (w_dgrad) {
+      const float sc = scale ? scale[co] : 1.f;
+      // dgrad operand uses the bf16-rounded forward weight times the fp32 scale
+      w_dgrad[(((int64_t)ci * kh + y) * kw + x) * Cout + co] = (bf16_t)((float)vb * sc);
+    }
+  }
+}
+
+extern "C" int tdn_pack_conv_weight(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int Cout,
+                                    int Cin, int kh, int kw, const float* scale, void* w_fwd, void* w_dgrad,
+                                    int dtype, void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(w && w_fwd, "tdn_pack_conv_weight: NULL pointer");
+  const int64_t total = (int64_t)Cout * Cin * kh * kw;
+  TDN_CHECK(total > 0, "tdn_pack_conv_weight: empty weight");
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, s_o, s_i,
+                     s_h, s_w, Cout, Cin, kh, kw, scale, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void pack_stem_kernel(const float* w, int Cout, bf16_t* w_fwd) {
+  const int total = Cout * 7 * 8 * 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i & 3, kw = (i >> 2) & 7, kh = (i >> 5) % 7, co = i / 224;
+    float v = 0.f;
+    if (c < 3 && kw < 7) v = w[co * 147 + c * 49 + kh * 7 + kw];
+    w_fwd[i] = (bf16_t)v;
+  }
+}
+
+extern "C" int tdn_pack_stem_weight(const float* w, int Cout, void* w_fwd, int dtype, void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(w && w_fwd && Cout > 0, "tdn_pack_stem_weight: bad arguments");
+  hipLaunchKernelGGL(pack_stem_kernel, dim3(grid_for(Cout * 224, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout,
+                     (bf16_t*)w_fwd);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- image staging: NCHW fp32 -> zero-padded NHWC4 bf16 [N][H+6][W+8][4] ----------------------
+__global__ void stage_image_kernel(const float* img, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N,
+                                   int H, int W, bf16_t* xp) {
+  const int Hp = H + 6, Wp = W + 8;
+  const int64_t total = (int64_t)N * Hp * Wp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int wp = (int)(i % Wp);
+    int64_t r = i / Wp;
+    const int hp = (int)(r % Hp);
+    const int n = (int)(r / Hp);
+    const int h = hp - 3, w = wp - 3;
+    bf16x4_t v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (h >= 0 && h < H && w >= 0 && w < W) {
+      const float* s = img + n * s_n + h * s_h + w * s_w;
+      v[0] = (bf16_t)s[0];
+      v[1] = (bf16_t)s[s_c];
+      v[2] = (bf16_t)s[2 * s_c];
+    }
+    *(bf16x4_t*)(xp + i * 4) = v;
+  }
+}
+
+extern "C" int tdn_stage_image(const float* img, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N, int H,
+                               int W, void* xp, int dtype, void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(img && xp && N > 0 && H > 0 && W > 0, "tdn_stage_image: bad arguments");
+  const int64_t total = (int64_t)N * (H + 6) * (W + 8);
+  hipLaunchKernelGGL(stage_image_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, s_n,
+                     s_c, s_h, s_w, N, H, W, (bf16_t*)xp);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- max pool 3x3 s2 p1 (NHWC, 8 channels per lane) --------------------------------------------
+__global__ void maxpool_fwd_kernel(const bf16_t* x, bf16_t* y, uint8_t* idx, int N, int H, int W, int C, int Ho,
+                                   int Wo) {
+  const int C8 = C >> 3;
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    int64_t r = i / C8;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = ho * 2 - 1 + kh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = wo * 2 - 1 + kw;
+        if (w < 0 || w >= W) continue;
+        const bf16x8_t v = *(const bf16x8_t*)(x + (((int64_t)n * H + h) * W + w) * C + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[e];
+          // PyTorch rule: first maximum in (kh, kw) scan order wins; NaN propagates
+          if (bi[e] < 0 || f > best[e] || f != f) { best[e] = f; bi[e] = kh * 3 + kw; }
+        }
+      }
+    }
+    bf16x8_t o;
+    uint64_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] = (bf16_t)best[e]; packed |= (uint64_t)(uint8_t)bi[e] << (8 * e); }
+    *(bf16x8_t*)(y + i * 8) = o;
+    *(uint64_t*)(idx + i * 8) = packed;
+  }
+}
+
+extern "C" int tdn_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype,
+                                    void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "tdn_maxpool3x3s2_fwd: bad arguments");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Gather form of the adjoint: each input element sums dy of the (<= 4) windows that selected it.
+__global__ void maxpool_bwd_kernel(const bf16_t* dy, const uint8_t* idx, const bf16_t* mask, bf16_t* dx, int N, int H,
+                                   int W, int C, int Ho, int Wo) {
+  const int C8 = C >> 3;
+  const int64_t total = (int64_t)N * H * W * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    int64_t r = i / C8;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // windows ho with ho*2-1+kh == h  ->  kh = h + 1 - 2*ho in [0,2]; ascending ho = PyTorch's accumulation order
+    const int ho_lo = max(0, (h - 1 + 1) / 2), ho_hi = min(Ho - 1, (h + 1) / 2);
+    const int wo_lo = max(0, (w - 1 + 1) / 2), wo_hi = min(Wo - 1, (w + 1) / 2);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      const int kh = h + 1 - 2 * ho;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const int kw = w + 1 - 2 * wo;
+        const int code = kh * 3 + kw;
+        const int64_t o = ((((int64_t)n * Ho + ho) * Wo + wo) * C8 + c8) * 8;
+        const uint64_t pk = *(const uint64_t*)(idx + o);
+        const bf16x8_t g = *(const bf16x8_t*)(dy + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if ((int)((pk >> (8 * e)) & 0xff) == code) acc[e] += (float)g[e];
+      }
+    }
+    bf16x8_t o8;
+    if (mask) {
+      const bf16x8_t mk = *(const bf16x8_t*)(mask + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)(((float)mk[e] > 0.f) ? acc[e] : 0.f);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)acc[e];
+    }
+    *(bf16x8_t*)(dx + i * 8) = o8;
+  }
+}
+
+extern "C" int tdn_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, const void* mask_src, void* dx, int N,
+                                    int H, int W, int C, int dtype, void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "tdn_maxpool3x3s2_bwd: bad arguments");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, idx, (const bf16_t*)mask_src, (bf16_t*)dx, N, H, W, C, Ho, Wo);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- stride-2 subsample (F.max_pool2d(x, 1, stride=2)) -------------------------------------------
+__global__ void subsample_fwd_kernel(const bf16_t* x, bf16_t* y, int N, int H, int W, int C, int Ho, int Wo) {
+  const int C8 = C >> 3;
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    int64_t r = i / C8;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    *(bf16x8_t*)(y + i * 8) = *(const bf16x8_t*)(x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + c8 * 8);
+  }
+}
+
+extern "C" int tdn_subsample2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "tdn_subsample2_fwd: bad arguments");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  hipLaunchKernelGGL(subsample_fwd_kernel, dim3(grid_for((int64_t)N * Ho * Wo * (C / 8), 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void subsample_bwd_kernel(const bf16_t* dy, const bf16_t* dx_in, bf16_t* dx, int N, int H, int W, int C,
+                                     int Ho, int Wo) {
+  const int C8 = C >> 3;
+  const int64_t total = (int64_t)N * H * W * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    int64_t r = i / C8;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[8];
+    if (dx_in) {
+      const bf16x8_t v = *(const bf16x8_t*)(dx_in + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = (float)v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    }
+    if (((h | w) & 1) == 0) {
+      const bf16x8_t g = *(const bf16x8_t*)(dy + ((((int64_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C8 + c8) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)g[e];
+    }
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
+    *(bf16x8_t*)(dx + i * 8) = o;
+  }
+}
+
+extern "C" int tdn_subsample2_bwd(const void* dy, const void* dx_in, void* dx, int N, int H, int W, int C, int dtype,
+                                  void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "tdn_subsample2_bwd: bad arguments");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  hipLaunchKernelGGL(subsample_bwd_kernel, dim3(grid_for((int64_t)N * H * W * (C / 8), 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dx_in, (bf16_t*)dx, N, H, W, C, Ho, Wo);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- out = (a + b) masked by mask > 0 ---------------------------------------------------------------
+__global__ void add_relu_mask_kernel(const bf16_t* a, const bf16_t* b, const bf16_t* mask, bf16_t* out, int64_t n8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const bf16x8_t va = *(const bf16x8_t*)(a + i * 8);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)va[e];
+    if (b) {
+      const bf16x8_t vb = *(const bf16x8_t*)(b + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)vb[e];
+    }
+    if (mask) {
+      const bf16x8_t mk = *(const bf16x8_t*)(mask + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ((float)mk[e] > 0.f) ? v[e] : 0.f;
+    }
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *(bf16x8_t*)(out + i * 8) = o;
+  }
+}
+
+extern "C" int tdn_add_relu_mask(const void* a, const void* b, const void* mask_src, void* out, int64_t n, int dtype,
+                                 void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(a && out && n > 0 && n % 8 == 0, "tdn_add_relu_mask: bad arguments (n=%lld)", (long long)n);
+  hipLaunchKernelGGL(add_relu_mask_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)mask_src, (bf16_t*)out, n / 8);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- boundary layout converters -----------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N,
+                                    int C, int H, int W, bf16_t* dst) {
+  // tile transpose through LDS: 32 pixels x 32 channels per block step
+  __shared__ float t[32][33];
+  const int HW = H * W;
+  const int tiles_p = ceil_div(HW, 32), tiles_c = ceil_div(C, 32);
+  const int64_t ntiles = (int64_t)N * tiles_p * tiles_c;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty in 0..7
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tc = (int)(tile % tiles_c);
+    int64_t r = tile / tiles_c;
+    const int tp = (int)(r % tiles_p);
+    const int n = (int)(r / tiles_p);
+    for (int k = ty; k < 32; k += 8) {
+      const int c = tc * 32 + k, pix = tp * 32 + tx;
+      float v = 0.f;
+      if (c < C && pix < HW) {
+        const int h = pix / W, w = pix - h * W;
+        v = src[n * s_n + c * s_c + h * s_h + w * s_w];
+      }
+      t[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      const int pix = tp * 32 + k, c = tc * 32 + tx;
+      if (c < C && pix < HW) dst[((int64_t)n * HW + pix) * C + c] = (bf16_t)t[tx][k];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int tdn_nchw_f32_to_nhwc(const float* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N,
+                                    int C, int H, int W, void* dst, int dtype, void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "tdn_nchw_f32_to_nhwc: bad arguments");
+  const int64_t ntiles = (int64_t)N * ceil_div(H * W, 32) * ceil_div(C, 32);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((int)(ntiles < 8192 ? ntiles : 8192)), dim3(256), 0,
+                     (hipStream_t)stream, src, s_n, s_c, s_h, s_w, N, C, H, W, (bf16_t*)dst);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void nhwc_to_nchw_kernel(const bf16_t* src, int N, int C, int H, int W, float* dst) {
+  __shared__ float t[32][33];
+  const int HW = H * W;
+  const int tiles_p = ceil_div(HW, 32), tiles_c = ceil_div(C, 32);
+  const int64_t ntiles = (int64_t)N * tiles_p * tiles_c;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tc = (int)(tile % tiles_c);
+    int64_t r = tile / tiles_c;
+    const int tp = (int)(r % tiles_p);
+    const int n = (int)(r / tiles_p);
+    for (int k = ty; k < 32; k += 8) {
+      const int pix = tp * 32 + k, c = tc * 32 + tx;
+      t[k][tx] = (c < C && pix < HW) ? (float)src[((int64_t)n * HW + pix) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      const int c = tc * 32 + k, pix = tp * 32 + tx;
+      if (c < C && pix < HW) dst[((int64_t)n * C + c) * HW + pix] = t[tx][k];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int tdn_nhwc_to_nchw_f32(const void* src, int N, int C, int H, int W, float* dst, int dtype,
+                                    void* stream) {
+  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "tdn_nhwc_to_nchw_f32: bad arguments");
+  const int64_t ntiles = (int64_t)N * ceil_div(H * W, 32) * ceil_div(C, 32);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((int)(ntiles < 8192 ? ntiles : 8192)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)src, N, C, H, W, dst);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}

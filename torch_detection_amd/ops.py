@@ -1,0 +1,375 @@
+"""Host-side operator layer: torch tensors in, C-ABI calls out (libtdn.so, include/tdn.h).
+
+Activations are NHWC bfloat16 tensors of shape (N, H, W, C), contiguous.  Every function validates
+shapes on the host before launching (a mis-shaped launch can fault the GPU), enqueues on PyTorch's
+current HIP stream, and never synchronises.  There is no non-HIP fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ADD_NONE, ADD_SAME, ADD_SUMPOOL2, ADD_UP2X, TDN_BF16, Epilogue  # noqa: F401
+
+BF16 = torch.bfloat16
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk_act(t, name, C=None):
+    if t.dtype != BF16 or not t.is_cuda or t.dim() != 4 or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous CUDA bfloat16 NHWC tensor, got %s %s %s" %
+                         (name, t.dtype, t.device, tuple(t.shape)))
+    if C is not None and t.shape[3] != C:
+        raise ValueError("%s: expected %d channels, got %d" % (name, C, t.shape[3]))
+
+
+def _chk_vec(t, name, C):
+    if t is None:
+        return
+    if t.dtype != torch.float32 or not t.is_cuda or t.numel() != C or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous CUDA float32 vector of %d elements" % (name, C))
+
+
+def conv_out_size(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+def make_epilogue(Cout, Ho, Wo, scale=None, shift=None, addend=None, addend_mode=ADD_NONE, relu=False,
+                  mask_src=None, N=None, out_f32=False):
+    _chk_vec(scale, "scale", Cout)
+    _chk_vec(shift, "shift", Cout)
+    ep = Epilogue()
+    ep.scale = scale.data_ptr() if scale is not None else None
+    ep.shift = shift.data_ptr() if shift is not None else None
+    ep.relu = 1 if relu else 0
+    ep.out_f32 = 1 if out_f32 else 0
+    ep.addend_mode = ADD_NONE
+    if addend is not None and addend_mode != ADD_NONE:
+        _chk_act(addend, "addend", Cout)
+        exp = {ADD_SAME: (Ho, Wo), ADD_UP2X: (Ho // 2, Wo // 2), ADD_SUMPOOL2: (Ho * 2, Wo * 2)}[addend_mode]
+        if tuple(addend.shape[1:3]) != exp or (addend_mode == ADD_UP2X and (Ho % 2 or Wo % 2)) or \
+                (N is not None and addend.shape[0] != N):
+            raise RuntimeError("epilogue addend of spatial size %s does not match output %s (mode %d)" %
+                               (tuple(addend.shape[1:3]), (Ho, Wo), addend_mode))
+        ep.addend = addend.data_ptr()
+        ep.addend_mode = addend_mode
+        ep.addend_h, ep.addend_w = addend.shape[1], addend.shape[2]
+    if mask_src is not None:
+        _chk_act(mask_src, "mask_src", Cout)
+        if tuple(mask_src.shape[1:3]) != (Ho, Wo) or (N is not None and mask_src.shape[0] != N):
+            raise RuntimeError("mask_src shape %s does not match output" % (tuple(mask_src.shape),))
+        ep.mask_src = mask_src.data_ptr()
+    return ep
+
+
+def bn_fold(gamma, beta, mean, var, eps):
+    """(scale, shift, invstd) of an eval-mode BatchNorm2d (layers.py:50-54)."""
+    C = gamma.numel()
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (mean, "running_mean"), (var, "running_var")):
+        _chk_vec(t.detach(), n, C)
+    out = torch.empty(3, C, dtype=torch.float32, device=gamma.device)
+    _lib.check(_lib.load().tdn_bn_fold(_ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), float(eps), C,
+                                       _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _lib.stream_ptr()), "tdn_bn_fold")
+    return out[0], out[1], out[2]
+
+
+def pack_conv_weight(w, scale=None, want_dgrad=True):
+    """fp32 OIHW (any strides) -> (w_fwd bf16 [O][kh][kw][I], w_dgrad bf16 [I][kh][kw][O] with scale folded)."""
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_cuda or w.dim() != 4:
+        raise ValueError("weight must be a CUDA float32 4-D tensor")
+    O, I, kh, kw = w.shape
+    _chk_vec(scale, "scale", O)
+    w_fwd = torch.empty(O, kh, kw, I, dtype=BF16, device=w.device)
+    w_dg = torch.empty(I, kh, kw, O, dtype=BF16, device=w.device) if want_dgrad else None
+    s = w.stride()
+    _lib.check(_lib.load().tdn_pack_conv_weight(_ptr(w), s[0], s[1], s[2], s[3], O, I, kh, kw, _ptr(scale),
+                                                _ptr(w_fwd), _ptr(w_dg), TDN_BF16, _lib.stream_ptr()),
+               "tdn_pack_conv_weight")
+    return w_fwd, w_dg
+
+
+def pack_stem_weight(w):
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_cuda or tuple(w.shape[1:]) != (3, 7, 7) or not w.is_contiguous():
+        raise ValueError("stem weight must be a contiguous CUDA float32 [Cout,3,7,7] tensor")
+    O = w.shape[0]
+    out = torch.empty(O, 7, 8, 4, dtype=BF16, device=w.device)
+    _lib.check(_lib.load().tdn_pack_stem_weight(_ptr(w), O, _ptr(out), TDN_BF16, _lib.stream_ptr()),
+               "tdn_pack_stem_weight")
+    return out
+
+
+def conv2d_fwd(x, w_fwd, k, stride, pad, scale=None, shift=None, addend=None, addend_mode=ADD_NONE, relu=False,
+               out_f32=False):
+    _chk_act(x, "x")
+    N, H, W, Cin = x.shape
+    Cout = w_fwd.shape[0]
+    if w_fwd.dtype != BF16 or tuple(w_fwd.shape) != (Cout, k, k, Cin) or not w_fwd.is_contiguous():
+        raise ValueError("w_fwd must be bf16 [Cout,k,k,Cin] contiguous, got %s" % (tuple(w_fwd.shape),))
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    y = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    ep = make_epilogue(Cout, Ho, Wo, scale, shift, addend, addend_mode, relu, None, N, out_f32)
+    _lib.check(_lib.load().tdn_conv2d_fwd(_ptr(x), _ptr(w_fwd), _ptr(y), N, H, W, Cin, Cout, k, stride, pad,
+                                          ctypes.byref(ep), TDN_BF16, _lib.stream_ptr()), "tdn_conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(g, w_dgrad, in_hw, k, stride, pad, addend=None, addend_mode=ADD_NONE, mask_src=None,
+                 out_f32=False):
+    """dx (N,H,W,Cin) from g (N,Ho,Wo,Cout); epilogue: + addend, then ReLU mask by mask_src > 0."""
+    _chk_act(g, "g")
+    N, Ho, Wo, Cout = g.shape
+    H, W = in_hw
+    Cin = w_dgrad.shape[0]
+    if w_dgrad.dtype != BF16 or tuple(w_dgrad.shape) != (Cin, k, k, Cout) or not w_dgrad.is_contiguous():
+        raise ValueError("w_dgrad must be bf16 [Cin,k,k,Cout] contiguous, got %s" % (tuple(w_dgrad.shape),))
+    if (Ho, Wo) != (conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)):
+        raise RuntimeError("dgrad: g spatial size %s inconsistent with input %s" % ((Ho, Wo), (H, W)))
+    dx = torch.empty(N, H, W, Cin, dtype=torch.float32 if out_f32 else BF16, device=g.device)
+    ep = make_epilogue(Cin, H, W, None, None, addend, addend_mode, False, mask_src, N, out_f32)
+    _lib.check(_lib.load().tdn_conv2d_dgrad(_ptr(g), _ptr(w_dgrad), _ptr(dx), N, H, W, Cin, Cout, k, stride, pad,
+                                            ctypes.byref(ep), TDN_BF16, _lib.stream_ptr()), "tdn_conv2d_dgrad")
+    return dx
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """One grow-only scratch buffer per device; all users are ordered on the current stream."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv2d_wgrad(x, g, w_fwd, k, stride, pad, scale=None, mean=None, invstd=None, dw=None, dgamma=None,
+                 dbeta=None, beta=0.0):
+    """Weight + affine grads. dw: fp32 [Cout,k,k,Cin] (written, or accumulated when beta=1)."""
+    _chk_act(x, "x")
+    _chk_act(g, "g")
+    N, H, W, Cin = x.shape
+    Cout = g.shape[3]
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    if tuple(g.shape) != (N, Ho, Wo, Cout) or tuple(w_fwd.shape) != (Cout, k, k, Cin):
+        raise RuntimeError("wgrad: inconsistent shapes x=%s g=%s w=%s" %
+                           (tuple(x.shape), tuple(g.shape), tuple(w_fwd.shape)))
+    dev = x.device
+    if dw is None:
+        dw = torch.empty(Cout, k, k, Cin, dtype=torch.float32, device=dev)
+    elif dw.dtype != torch.float32 or dw.numel() != Cout * k * k * Cin:
+        raise ValueError("dw has wrong dtype/size")
+    if dbeta is None:
+        dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
+    if mean is not None and dgamma is None:
+        dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+    for t, n in ((scale, "scale"), (mean, "mean"), (invstd, "invstd"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _chk_vec(t, n, Cout)
+    lib = _lib.load()
+    nbytes = lib.tdn_conv2d_wgrad_workspace(N, H, W, Cin, Cout, k, stride, pad)
+    ws = _workspace(nbytes, dev)
+    _lib.check(lib.tdn_conv2d_wgrad(_ptr(x), _ptr(g), _ptr(w_fwd), _ptr(scale), _ptr(mean), _ptr(invstd), _ptr(dw),
+                                    _ptr(dgamma), _ptr(dbeta), float(beta), N, H, W, Cin, Cout, k, stride, pad,
+                                    _ptr(ws), ws.numel(), TDN_BF16, _lib.stream_ptr()), "tdn_conv2d_wgrad")
+    return dw, dgamma, dbeta
+
+
+def stage_image(img):
+    """NCHW float32 image batch (any strides) -> zero-padded NHWC4 bf16 (N, H+6, W+8, 4)."""
+    if img.dtype != torch.float32 or not img.is_cuda or img.dim() != 4 or img.shape[1] != 3:
+        raise ValueError("image batch must be CUDA float32 (N,3,H,W), got %s %s" % (img.dtype, tuple(img.shape)))
+    N, _, H, W = img.shape
+    xp = torch.empty(N, H + 6, W + 8, 4, dtype=BF16, device=img.device)
+    s = img.stride()
+    _lib.check(_lib.load().tdn_stage_image(_ptr(img), s[0], s[1], s[2], s[3], N, H, W, _ptr(xp), TDN_BF16,
+                                           _lib.stream_ptr()), "tdn_stage_image")
+    return xp
+
+
+def stem_conv_fwd(xp, w_stem, hw, scale=None, shift=None, relu=True, out_f32=False):
+    H, W = hw
+    N = xp.shape[0]
+    Cout = w_stem.shape[0]
+    if tuple(xp.shape) != (N, H + 6, W + 8, 4) or xp.dtype != BF16 or not xp.is_contiguous():
+        raise ValueError("xp must be the staged image (N,H+6,W+8,4) bf16")
+    if tuple(w_stem.shape) != (Cout, 7, 8, 4) or w_stem.dtype != BF16:
+        raise ValueError("w_stem must be bf16 [Cout,7,8,4]")
+    if H % 2 or W % 2:
+        raise RuntimeError("stem conv needs even H and W (got %dx%d); pad the batch as the reference pipeline does "
+                           "(size_divisor, datasets/utils/image.py:326-347)" % (H, W))
+    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32 if out_f32 else BF16, device=xp.device)
+    ep = make_epilogue(Cout, H // 2, W // 2, scale, shift, None, ADD_NONE, relu, None, N, out_f32)
+    _lib.check(_lib.load().tdn_stem_conv_fwd(_ptr(xp), _ptr(w_stem), _ptr(y), N, H, W, Cout, ctypes.byref(ep),
+                                             TDN_BF16, _lib.stream_ptr()), "tdn_stem_conv_fwd")
+    return y
+
+
+def stem_conv_wgrad(xp, g, w_stem, hw, scale=None, mean=None, invstd=None, dw=None, dgamma=None, dbeta=None,
+                    beta=0.0):
+    H, W = hw
+    N = xp.shape[0]
+    Cout = w_stem.shape[0]
+    _chk_act(g, "g", Cout)
+    if tuple(g.shape) != (N, H // 2, W // 2, Cout) or tuple(xp.shape) != (N, H + 6, W + 8, 4):
+        raise RuntimeError("stem wgrad: inconsistent shapes")
+    dev = g.device
+    if dw is None:
+        dw = torch.empty(Cout, 3, 7, 7, dtype=torch.float32, device=dev)
+    if dbeta is None:
+        dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
+    if mean is not None and dgamma is None:
+        dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+    for t, n in ((scale, "scale"), (mean, "mean"), (invstd, "invstd"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _chk_vec(t, n, Cout)
+    lib = _lib.load()
+    nbytes = lib.tdn_stem_conv_wgrad_workspace(N, H, W, Cout)
+    ws = _workspace(nbytes, dev)
+    _lib.check(lib.tdn_stem_conv_wgrad(_ptr(xp), _ptr(g), _ptr(w_stem), _ptr(scale), _ptr(mean), _ptr(invstd),
+                                       _ptr(dw), _ptr(dgamma), _ptr(dbeta), float(beta), N, H, W, Cout, _ptr(ws),
+                                       ws.numel(), TDN_BF16, _lib.stream_ptr()), "tdn_stem_conv_wgrad")
+    return dw, dgamma, dbeta
+
+
+def maxpool3x3s2_fwd(x):
+    _chk_act(x, "x")
+    N, H, W, C = x.shape
+    Ho, Wo = conv_out_size(H, 3, 2, 1), conv_out_size(W, 3, 2, 1)
+    y = torch.empty(N, Ho, Wo, C, dtype=BF16, device=x.device)
+    idx = torch.empty(N, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().tdn_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(idx), N, H, W, C, TDN_BF16,
+                                                _lib.stream_ptr()), "tdn_maxpool3x3s2_fwd")
+    return y, idx
+
+
+def maxpool3x3s2_bwd(dy, idx, in_hw, mask_src=None):
+    _chk_act(dy, "dy")
+    N, Ho, Wo, C = dy.shape
+    H, W = in_hw
+    if (Ho, Wo) != (conv_out_size(H, 3, 2, 1), conv_out_size(W, 3, 2, 1)) or tuple(idx.shape) != tuple(dy.shape):
+        raise RuntimeError("maxpool bwd: inconsistent shapes")
+    if mask_src is not None:
+        _chk_act(mask_src, "mask_src", C)
+        if tuple(mask_src.shape) != (N, H, W, C):
+            raise RuntimeError("maxpool bwd: mask_src shape mismatch")
+    dx = torch.empty(N, H, W, C, dtype=BF16, device=dy.device)
+    _lib.check(_lib.load().tdn_maxpool3x3s2_bwd(_ptr(dy), _ptr(idx), _ptr(mask_src), _ptr(dx), N, H, W, C, TDN_BF16,
+                                                _lib.stream_ptr()), "tdn_maxpool3x3s2_bwd")
+    return dx
+
+
+def subsample2_fwd(x):
+    _chk_act(x, "x")
+    N, H, W, C = x.shape
+    y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, C, dtype=BF16, device=x.device)
+    _lib.check(_lib.load().tdn_subsample2_fwd(_ptr(x), _ptr(y), N, H, W, C, TDN_BF16, _lib.stream_ptr()),
+               "tdn_subsample2_fwd")
+    return y
+
+
+def subsample2_bwd(dy, in_hw, dx_in=None):
+    _chk_act(dy, "dy")
+    N, Ho, Wo, C = dy.shape
+    H, W = in_hw
+    if (Ho, Wo) != ((H + 1) // 2, (W + 1) // 2):
+        raise RuntimeError("subsample bwd: inconsistent shapes")
+    if dx_in is not None:
+        _chk_act(dx_in, "dx_in", C)
+        if tuple(dx_in.shape) != (N, H, W, C):
+            raise RuntimeError("subsample bwd: dx_in shape mismatch")
+    dx = torch.empty(N, H, W, C, dtype=BF16, device=dy.device)
+    _lib.check(_lib.load().tdn_subsample2_bwd(_ptr(dy), _ptr(dx_in), _ptr(dx), N, H, W, C, TDN_BF16,
+                                              _lib.stream_ptr()), "tdn_subsample2_bwd")
+    return dx
+
+
+def add_relu_mask(a, b=None, mask_src=None):
+    _chk_act(a, "a")
+    for t in (b, mask_src):
+        if t is not None:
+            _chk_act(t, "operand")
+            if t.shape != a.shape:
+                raise RuntimeError("add_relu_mask: shape mismatch")
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().tdn_add_relu_mask(_ptr(a), _ptr(b), _ptr(mask_src), _ptr(out), a.numel(), TDN_BF16,
+                                             _lib.stream_ptr()), "tdn_add_relu_mask")
+    return out
+
+
+def to_nhwc_bf16(x):
+    """Logical NCHW tensor -> NHWC bf16 (N,H,W,C). Zero-copy when x already is a permuted NHWC bf16 tensor."""
+    if x.dim() != 4 or not x.is_cuda:
+        raise ValueError("expected a 4-D CUDA tensor, got %s on %s" % (tuple(x.shape), x.device))
+    if x.dtype == BF16:
+        xp = x.permute(0, 2, 3, 1)
+        if xp.is_contiguous():
+            return xp
+        return xp.contiguous()
+    if x.dtype != torch.float32:
+        x = x.float()
+    N, C, H, W = x.shape
+    out = torch.empty(N, H, W, C, dtype=BF16, device=x.device)
+    s = x.stride()
+    _lib.check(_lib.load().tdn_nchw_f32_to_nhwc(_ptr(x), s[0], s[1], s[2], s[3], N, C, H, W, _ptr(out), TDN_BF16,
+                                                _lib.stream_ptr()), "tdn_nchw_f32_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw_f32(x):
+    _chk_act(x, "x")
+    N, H, W, C = x.shape
+    out = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().tdn_nhwc_to_nchw_f32(_ptr(x), N, C, H, W, _ptr(out), TDN_BF16, _lib.stream_ptr()),
+               "tdn_nhwc_to_nchw_f32")
+    return out
+
+
+# ---- box ops ---------------------------------------------------------------------------------------
+def _chk_boxes(b, name):
+    if b.dtype != torch.float32 or not b.is_cuda or b.dim() != 2 or b.shape[1] != 4 or not b.is_contiguous():
+        raise ValueError("%s must be a contiguous CUDA float32 (K,4) tensor" % name)
+
+
+def anchor_grid(base_anchors, featmap_size, stride, valid_size=None):
+    _chk_boxes(base_anchors, "base_anchors")
+    fh, fw = featmap_size
+    A = base_anchors.shape[0]
+    vh, vw = valid_size if valid_size is not None else (fh, fw)
+    dev = base_anchors.device
+    anchors = torch.empty(fh * fw * A, 4, dtype=torch.float32, device=dev)
+    valid = torch.empty(fh * fw * A, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.load().tdn_anchor_grid(_ptr(base_anchors), A, fh, fw, int(stride), int(vh), int(vw),
+                                           _ptr(anchors), _ptr(valid), _lib.stream_ptr()), "tdn_anchor_grid")
+    return anchors, valid
+
+
+def bbox_iou_pairwise(a, b):
+    _chk_boxes(a, "bboxes1")
+    _chk_boxes(b, "bboxes2")
+    out = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().tdn_bbox_iou_pairwise(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out),
+                                                 _lib.stream_ptr()), "tdn_bbox_iou_pairwise")
+    return out
+
+
+def nms(boxes, scores, iou_thr):
+    _chk_boxes(boxes, "boxes")
+    N = boxes.shape[0]
+    if scores.dtype != torch.float32 or not scores.is_cuda or scores.numel() != N or not scores.is_contiguous():
+        raise ValueError("scores must be a contiguous CUDA float32 (N,) tensor")
+    dev = boxes.device
+    keep = torch.zeros(N, dtype=torch.uint8, device=dev)
+    kept_idx = torch.empty(N, dtype=torch.int64, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    nbytes = lib.tdn_nms_workspace(N)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    _lib.check(lib.tdn_nms(_ptr(boxes), _ptr(scores), N, float(iou_thr), _ptr(keep), _ptr(kept_idx), _ptr(num),
+                           ctypes.c_void_p(ws.data_ptr() + off), nbytes, _lib.stream_ptr()), "tdn_nms")
+    return keep, kept_idx, num
