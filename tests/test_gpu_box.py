@@ -1,0 +1,117 @@
+"""GPU parity tests of the box ops (anchor grid / pairwise IoU / NMS): bit-exact against the C oracle.
+
+Parity is UNPINNED by the reference (core/ is empty): the oracle is oracle/box_ref.c,
+itself checked against the Appendix-B known answers in tests/test_oracle_box.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import box_ref as B
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from torch_detection_amd import ops as _ops
+    return _ops
+
+
+def rand_boxes(n, seed, integer):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.rand(n, generator=g) * (256 - 8) + 8
+    h = torch.rand(n, generator=g) * (256 - 8) + 8
+    x1 = torch.rand(n, generator=g) * (1344 - w)
+    y1 = torch.rand(n, generator=g) * (800 - h)
+    b = torch.stack([x1, y1, x1 + w, y1 + h], -1).float()
+    if integer:
+        b = b.floor()
+    s = torch.rand(n, generator=g).float()
+    return b.contiguous(), s.contiguous()
+
+
+LEVELS = [((200, 336), 4), ((100, 168), 8), ((50, 84), 16), ((25, 42), 32), ((13, 21), 64)]
+
+
+def test_anchor_grid_pyramid(ops):
+    total = 0
+    for (fh, fw), stride in LEVELS:
+        base = B.base_anchors(stride, [8], [0.5, 1.0, 2.0])
+        ref, vref = B.anchor_grid(base, (fh, fw), stride, (fh - 1, fw - 2))
+        a, v = ops.anchor_grid(torch.from_numpy(base).cuda(), (fh, fw), stride, (fh - 1, fw - 2))
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        assert np.array_equal(a.cpu().numpy().astype(np.int32), ref.astype(np.int32))
+        assert np.array_equal(v.cpu().numpy(), vref)
+        total += a.shape[0]
+    assert total == 268569
+
+
+def test_anchor_grid_edge(ops):
+    base = B.base_anchors(16, [8, 16, 32], [0.5, 1.0, 2.0])
+    a, v = ops.anchor_grid(torch.from_numpy(base).cuda(), (0, 5), 16)
+    assert a.shape == (0, 4) and v.shape == (0,)
+    a, v = ops.anchor_grid(torch.from_numpy(base).cuda(), (1, 1), 16)
+    assert np.array_equal(a.cpu().numpy(), base)
+
+
+@pytest.mark.parametrize("integer", [True, False])
+@pytest.mark.parametrize("n,m", [(1000, 1000), (10000, 100), (37, 53), (1, 1), (0, 5), (5, 0)])
+def test_iou_bit_exact(ops, n, m, integer):
+    a, _ = rand_boxes(n, 0, integer)
+    b, _ = rand_boxes(m, 1, integer)
+    ref = B.iou_pairwise(a.numpy(), b.numpy())
+    out = ops.bbox_iou_pairwise(a.cuda(), b.cuda())
+    assert out.shape == (n, m)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_iou_full_size_properties(ops):
+    # N = M = 10k (BASELINE config 3): symmetry, unit diagonal, range; 400 MB output
+    a, _ = rand_boxes(10000, 0, False)
+    out = ops.bbox_iou_pairwise(a.cuda(), a.cuda())
+    assert bool((out.diagonal() == 1).all())
+    assert torch.equal(out, out.t())
+    assert float(out.min()) >= 0 and float(out.max()) <= 1
+    rows = [0, 17, 9999]
+    ref = B.iou_pairwise(a[rows].numpy(), a.numpy())
+    assert np.array_equal(out[rows].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("integer", [True, False])
+@pytest.mark.parametrize("n", [10000, 1000, 65, 64, 63, 2, 1])
+def test_nms_bit_exact(ops, n, integer):
+    b, s = rand_boxes(n, 0, integer)
+    keep_ref, kept_ref, cnt = B.nms(b.numpy(), s.numpy(), 0.5)
+    keep, kept, num = ops.nms(b.cuda(), s.cuda(), 0.5)
+    assert int(num.item()) == cnt
+    assert np.array_equal(keep.cpu().numpy(), keep_ref)
+    assert np.array_equal(kept.cpu().numpy(), kept_ref)
+
+
+def test_nms_edge_cases(ops):
+    # N = 0
+    keep, kept, num = ops.nms(torch.zeros(0, 4).cuda(), torch.zeros(0).cuda(), 0.5)
+    assert keep.numel() == 0 and int(num.item()) == 0
+    # all-equal scores: index order decides
+    b, _ = rand_boxes(500, 3, True)
+    s = torch.full((500,), 0.5)
+    keep_ref, kept_ref, cnt = B.nms(b.numpy(), s.numpy(), 0.3)
+    keep, kept, num = ops.nms(b.cuda(), s.cuda(), 0.3)
+    assert np.array_equal(keep.cpu().numpy(), keep_ref) and np.array_equal(kept.cpu().numpy(), kept_ref)
+    # IoU exactly at the threshold is NOT suppressed (strict >): boxes [0,0,9,9] and [0,5,9,14]: inter 50, union 150
+    bb = torch.tensor([[0, 0, 9, 9], [0, 5, 9, 14], [100, 100, 110, 110]], dtype=torch.float32)
+    ss = torch.tensor([0.9, 0.8, 0.7])
+    thr = float(np.float32(50.0) / np.float32(150.0))
+    keep, kept, num = ops.nms(bb.cuda(), ss.cuda(), thr)
+    assert keep.cpu().tolist() == [1, 1, 1] and int(num.item()) == 3
+    keep, kept, num = ops.nms(bb.cuda(), ss.cuda(), np.nextafter(np.float32(thr), np.float32(0)).item())
+    assert keep.cpu().tolist() == [1, 0, 1] and kept.cpu().tolist() == [0, 2, -1]
+    # idempotence: NMS of the kept set keeps everything
+    b, s = rand_boxes(3000, 5, False)
+    keep, kept, num = ops.nms(b.cuda(), s.cuda(), 0.5)
+    k = int(num.item())
+    sel = kept[:k]
+    keep2, _, num2 = ops.nms(b.cuda()[sel].contiguous(), s.cuda()[sel].contiguous(), 0.5)
+    assert int(num2.item()) == k and bool(keep2.all())

@@ -1,0 +1,280 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against plain PyTorch fp32 on CPU.
+
+Operands are bf16-representable, accumulation is fp32.  Tolerances (written here, used below):
+  * forward / dgrad with fp32 output (pre-rounding value): max|err| / max|ref| <= 1e-3   (north-star figure)
+  * the same kernels with bf16 output: <= 1 bf16 ulp of the bf16-rounded reference (2^-7 relative, loose bound)
+  * wgrad (fp32 output, K up to N*H*W): rel-L2 <= 1e-3
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import det_tensor, max_rel, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from torch_detection_amd import ops as _ops
+    from torch_detection_amd import _lib
+    _lib.load()
+    return _ops
+
+
+def nhwc(t):  # NCHW float cpu -> NHWC bf16 cuda
+    return t.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+
+
+def nchw(t):  # NHWC cuda -> NCHW float cpu
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def pack_w(w):  # OIHW float (bf16-representable) -> [O][kh][kw][I] bf16 cuda
+    return w.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+
+
+def pack_wd(w, scale=None):  # -> [I][kh][kw][O] bf16 cuda with scale folded
+    ws = w if scale is None else w * scale.view(-1, 1, 1, 1)
+    return ws.permute(1, 2, 3, 0).contiguous().bfloat16().cuda()
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride
+    (1, 20, 24, 64, 256, 1, 1),
+    (2, 10, 12, 256, 64, 1, 1),
+    (1, 20, 24, 64, 64, 3, 1),
+    (2, 25, 42, 128, 128, 3, 2),
+    (1, 12, 16, 256, 512, 1, 2),
+    (1, 13, 21, 128, 128, 3, 1),
+    (1, 25, 43, 64, 128, 1, 2),
+]
+
+
+@pytest.mark.parametrize("tile", [None, "128x128", "128x64", "64x128", "64x64"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(ops, case, tile):
+    N, H, W, Cin, Cout, k, s = case
+    if tile and Cout % int(tile.split("x")[1]) != 0:
+        pytest.skip("tile does not divide Cout")
+    os.environ.pop("TDN_TILE", None)
+    if tile:
+        os.environ["TDN_TILE"] = tile
+    try:
+        x = det_tensor((N, Cin, H, W), 1, -1, 1)
+        w = det_tensor((Cout, Cin, k, k), 2, -0.2, 0.2)
+        scale = det_tensor((Cout,), 3, 0.5, 1.5, bf16=False)
+        shift = det_tensor((Cout,), 4, -0.5, 0.5, bf16=False)
+        ref = F.conv2d(x, w, None, s, k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        res = det_tensor(tuple(ref.shape), 5, -1, 1)
+        ref_r = F.relu(ref + res)
+        xg, wg = nhwc(x), pack_w(w)
+        y32 = ops.conv2d_fwd(xg, wg, k, s, k // 2, scale.cuda(), shift.cuda(), nhwc(res), ops.ADD_SAME, True,
+                             out_f32=True)
+        assert max_rel(nchw(y32), ref_r) <= TOL
+        y16 = ops.conv2d_fwd(xg, wg, k, s, k // 2, scale.cuda(), shift.cuda(), nhwc(res), ops.ADD_SAME, True)
+        err = (nchw(y16) - ref_r).abs()
+        assert bool((err <= ref_r.abs() * 2 ** -7 + 1e-6).all())
+        # no epilogue at all
+        y0 = ops.conv2d_fwd(xg, wg, k, s, k // 2, out_f32=True)
+        assert max_rel(nchw(y0), F.conv2d(x, w, None, s, k // 2)) <= TOL
+    finally:
+        os.environ.pop("TDN_TILE", None)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad(ops, case):
+    N, H, W, Cin, Cout, k, s = case
+    Ho, Wo = ops.conv_out_size(H, k, s, k // 2), ops.conv_out_size(W, k, s, k // 2)
+    g = det_tensor((N, Cout, Ho, Wo), 11, -1, 1)
+    w = det_tensor((Cout, Cin, k, k), 12, -0.2, 0.2)
+    scale = det_tensor((Cout,), 13, 0.5, 1.5)
+    wd = pack_wd(w, scale)  # bf16(scale*w)
+    w_eff = wd.float().cpu().permute(3, 0, 1, 2).contiguous()  # OIHW of the folded, rounded weights
+    xz = torch.zeros(N, Cin, H, W, requires_grad=True)
+    F.conv2d(xz, w_eff, None, s, k // 2).backward(g)
+    ref = xz.grad
+    dx = ops.conv2d_dgrad(nhwc(g), wd, (H, W), k, s, k // 2, out_f32=True)
+    assert max_rel(nchw(dx), ref) <= TOL
+    # fused epilogue: + addend, ReLU mask
+    add = det_tensor((N, Cin, H, W), 14, -1, 1)
+    msk = det_tensor((N, Cin, H, W), 15, -1, 1)
+    ref2 = (ref + add) * (msk > 0).float()
+    dx2 = ops.conv2d_dgrad(nhwc(g), wd, (H, W), k, s, k // 2, nhwc(add), ops.ADD_SAME, nhwc(msk), out_f32=True)
+    assert max_rel(nchw(dx2), ref2) <= TOL
+    dx3 = ops.conv2d_dgrad(nhwc(g), wd, (H, W), k, s, k // 2, nhwc(add), ops.ADD_SAME, nhwc(msk))
+    err = (nchw(dx3) - ref2).abs()
+    assert bool((err <= ref2.abs() * 2 ** -7 + 1e-6).all())
+
+
+def test_conv_epilogue_up2x_and_sumpool(ops):
+    N, H, W, C = 2, 8, 12, 64
+    x = det_tensor((N, 128, H, W), 21, -1, 1)
+    w = det_tensor((C, 128, 1, 1), 22, -0.2, 0.2)
+    bias = det_tensor((C,), 23, -0.5, 0.5, bf16=False)
+    coarse = det_tensor((N, C, H // 2, W // 2), 24, -1, 1)
+    ref = F.conv2d(x, w, bias) + F.interpolate(coarse, scale_factor=2, mode="nearest")
+    y = ops.conv2d_fwd(nhwc(x), pack_w(w), 1, 1, 0, None, bias.cuda(), nhwc(coarse), ops.ADD_UP2X, False, out_f32=True)
+    assert max_rel(nchw(y), ref) <= TOL
+    # adjoint: dgrad of a 3x3 conv + 2x2 sum-pool of the finer gradient
+    g = det_tensor((N, C, H, W), 25, -1, 1)
+    w3 = det_tensor((C, C, 3, 3), 26, -0.2, 0.2)
+    fine = det_tensor((N, C, 2 * H, 2 * W), 27, -1, 1)
+    xz = torch.zeros(N, C, H, W, requires_grad=True)
+    F.conv2d(xz, w3, None, 1, 1).backward(g)
+    ref2 = xz.grad + F.avg_pool2d(fine, 2) * 4
+    dx = ops.conv2d_dgrad(nhwc(g), pack_wd(w3), (H, W), 3, 1, 1, nhwc(fine), ops.ADD_SUMPOOL2, None, out_f32=True)
+    assert max_rel(nchw(dx), ref2) <= TOL
+    with pytest.raises(RuntimeError):
+        ops.conv2d_fwd(nhwc(x), pack_w(w), 1, 1, 0, None, None, nhwc(det_tensor((N, C, 3, 6), 1)), ops.ADD_UP2X)
+
+
+@pytest.mark.parametrize("case", CONV_CASES + [(2, 40, 48, 64, 64, 3, 1), (2, 16, 16, 512, 512, 3, 1)])
+@pytest.mark.parametrize("bn", [True, False])
+def test_conv_wgrad(ops, case, bn):
+    N, H, W, Cin, Cout, k, s = case
+    Ho, Wo = ops.conv_out_size(H, k, s, k // 2), ops.conv_out_size(W, k, s, k // 2)
+    x = det_tensor((N, Cin, H, W), 31, -1, 1)
+    g = det_tensor((N, Cout, Ho, Wo), 32, -1, 1)
+    w = det_tensor((Cout, Cin, k, k), 33, -0.2, 0.2).requires_grad_(True)
+    gamma = det_tensor((Cout,), 34, 0.5, 1.5, bf16=False).requires_grad_(True)
+    beta = det_tensor((Cout,), 35, -0.5, 0.5, bf16=False).requires_grad_(True)
+    mean = det_tensor((Cout,), 36, -0.2, 0.2, bf16=False)
+    var = det_tensor((Cout,), 37, 0.5, 1.5, bf16=False)
+    y = F.conv2d(x, w, None, s, k // 2)
+    if bn:
+        y = F.batch_norm(y, mean, var, gamma, beta, False, 0.1, 1e-5)
+    else:
+        y = y + beta.view(1, -1, 1, 1)
+    y.backward(g)
+    wf = pack_w(w.detach())
+    if bn:
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        scale = (gamma.detach() * invstd)
+        dw, dg, db = ops.conv2d_wgrad(nhwc(x), nhwc(g), wf, k, s, k // 2, scale.cuda(), mean.cuda(), invstd.cuda())
+        assert rel_l2(dg.cpu(), gamma.grad) <= TOL
+    else:
+        dw, dg, db = ops.conv2d_wgrad(nhwc(x), nhwc(g), wf, k, s, k // 2)
+    assert rel_l2(dw.cpu().permute(0, 3, 1, 2), w.grad) <= TOL
+    assert rel_l2(db.cpu(), beta.grad) <= TOL
+    # accumulate mode (beta=1): second call doubles
+    dw2, _, db2 = ops.conv2d_wgrad(nhwc(x), nhwc(g), wf, k, s, k // 2,
+                                   *( (scale.cuda(), mean.cuda(), invstd.cuda()) if bn else (None, None, None)),
+                                   dw=dw.clone(), dgamma=dg.clone() if bn else None, dbeta=db.clone(), beta=1.0)
+    assert rel_l2(dw2.cpu().permute(0, 3, 1, 2), 2 * w.grad) <= TOL
+    assert rel_l2(db2.cpu(), 2 * beta.grad) <= TOL
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 48), (2, 64, 96)])
+def test_stem(ops, shape):
+    N, H, W = shape
+    img = det_tensor((N, 3, H, W), 41, -2, 2)
+    w = det_tensor((64, 3, 7, 7), 42, -0.2, 0.2).requires_grad_(True)
+    gamma = det_tensor((64,), 43, 0.5, 1.5, bf16=False).requires_grad_(True)
+    beta = det_tensor((64,), 44, -0.5, 0.5, bf16=False).requires_grad_(True)
+    mean = det_tensor((64,), 45, -0.2, 0.2, bf16=False)
+    var = det_tensor((64,), 46, 0.5, 1.5, bf16=False)
+    pre = F.batch_norm(F.conv2d(img, w, None, 2, 3), mean, var, gamma, beta, False, 0.1, 1e-5)
+    ref = F.relu(pre)
+    xp = ops.stage_image(img.cuda())
+    # staging: interior equals the image, halo is zero
+    xpc = xp.float().cpu()
+    assert torch.equal(xpc[:, 3:3 + H, 3:3 + W, :3], img.permute(0, 2, 3, 1))
+    assert float(xpc[:, :3].abs().sum()) == 0 and float(xpc[..., 3].abs().sum()) == 0
+    ws = ops.pack_stem_weight(w.detach().cuda())
+    scale, shift, invstd = ops.bn_fold(gamma.detach().cuda(), beta.detach().cuda(), mean.cuda(), var.cuda(), 1e-5)
+    y = ops.stem_conv_fwd(xp, ws, (H, W), scale, shift, True, out_f32=True)
+    assert max_rel(nchw(y), ref) <= TOL
+    # wgrad
+    g = det_tensor(tuple(ref.shape), 47, -1, 1)
+    pre.backward(g)
+    dw, dg, db = ops.stem_conv_wgrad(xp, nhwc(g), ws, (H, W), scale, mean.cuda(), invstd)
+    assert rel_l2(dw.cpu(), w.grad) <= TOL
+    assert rel_l2(dg.cpu(), gamma.grad) <= TOL
+    assert rel_l2(db.cpu(), beta.grad) <= TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 24, 64), (1, 15, 21, 64), (1, 8, 8, 128)])
+def test_maxpool(ops, shape):
+    N, H, W, C = shape
+    # quantise so that ties are common (post-ReLU activations have many equal zeros)
+    x = (det_tensor((N, C, H, W), 51, -2, 2) * 2).round() / 2
+    x = F.relu(x).requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = det_tensor(tuple(y.shape), 52, -1, 1)
+    y.backward(dy)
+    yg, idx = ops.maxpool3x3s2_fwd(nhwc(x.detach()))
+    assert torch.equal(nchw(yg), y.detach())
+    dx = ops.maxpool3x3s2_bwd(nhwc(dy), idx, (H, W))
+    assert max_rel(nchw(dx), x.grad) <= 2 ** -7
+    # fused ReLU mask of the stem output
+    dxm = ops.maxpool3x3s2_bwd(nhwc(dy), idx, (H, W), nhwc(x.detach()))
+    assert max_rel(nchw(dxm), x.grad * (x.detach() > 0).float()) <= 2 ** -7
+
+
+def test_subsample_and_mask(ops):
+    x = det_tensor((2, 64, 25, 42), 61, -1, 1)
+    y = ops.subsample2_fwd(nhwc(x))
+    assert torch.equal(nchw(y), F.max_pool2d(x, 1, stride=2))
+    dy = det_tensor((2, 64, 13, 21), 62, -1, 1)
+    base = det_tensor((2, 64, 25, 42), 63, -1, 1)
+    ref = base.clone()
+    ref[:, :, ::2, ::2] += dy
+    dx = ops.subsample2_bwd(nhwc(dy), (25, 42), nhwc(base))
+    assert max_rel(nchw(dx), ref) <= 2 ** -7
+    dx0 = ops.subsample2_bwd(nhwc(dy), (25, 42))
+    ref0 = torch.zeros_like(base)
+    ref0[:, :, ::2, ::2] = dy
+    assert torch.equal(nchw(dx0), ref0)
+    a, b, m = (det_tensor((2, 64, 8, 8), s, -1, 1) for s in (64, 65, 66))
+    out = ops.add_relu_mask(nhwc(a), nhwc(b), nhwc(m))
+    assert max_rel(nchw(out), (a + b) * (m > 0).float()) <= 2 ** -7
+
+
+def test_layout_converters(ops):
+    x = det_tensor((2, 70, 9, 13), 71, -1, 1)
+    xg = x.cuda()
+    y = ops.to_nhwc_bf16(xg)
+    assert torch.equal(y.float().cpu(), x.permute(0, 2, 3, 1))
+    # strided (channels_last) source
+    y2 = ops.to_nhwc_bf16(xg.contiguous(memory_format=torch.channels_last))
+    assert torch.equal(y2, y)
+    back = ops.nhwc_to_nchw_f32(y)
+    assert torch.equal(back.cpu(), x)
+    # zero-copy for permuted bf16 NHWC
+    z = y.permute(0, 3, 1, 2)
+    assert ops.to_nhwc_bf16(z).data_ptr() == y.data_ptr()
+
+
+def test_pack_and_fold(ops):
+    w = det_tensor((128, 64, 3, 3), 81, -1, 1, bf16=False)
+    scale = det_tensor((128,), 82, 0.5, 1.5, bf16=False)
+    wf, wd = ops.pack_conv_weight(w.cuda(), scale.cuda())
+    assert torch.equal(wf.float().cpu(), w.bfloat16().float().permute(0, 2, 3, 1))
+    ref_d = (w.bfloat16().float() * scale.view(-1, 1, 1, 1)).bfloat16().float().permute(1, 2, 3, 0)
+    assert torch.equal(wd.float().cpu(), ref_d)
+    # channels_last-strided parameter gives the same packing
+    wcl = w.cuda().contiguous(memory_format=torch.channels_last)
+    wf2, _ = ops.pack_conv_weight(wcl, scale.cuda())
+    assert torch.equal(wf2, wf)
+    g, b, m, v = (det_tensor((128,), s, lo, hi, bf16=False) for s, lo, hi in
+                  ((83, 0.5, 1.5), (84, -1, 1), (85, -1, 1), (86, 0.5, 1.5)))
+    sc, sh, inv = ops.bn_fold(g.cuda(), b.cuda(), m.cuda(), v.cuda(), 1e-5)
+    inv_ref = 1.0 / torch.sqrt(v + 1e-5)
+    assert torch.allclose(inv.cpu(), inv_ref, rtol=1e-6, atol=0)
+    assert torch.allclose(sc.cpu(), g * inv_ref, rtol=1e-6, atol=0)
+    assert torch.allclose(sh.cpu(), b - m * g * inv_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_bad_shapes_fail_loudly(ops):
+    x = nhwc(det_tensor((1, 48, 8, 8), 1))
+    w = pack_w(det_tensor((64, 48, 1, 1), 2))
+    with pytest.raises(RuntimeError):
+        ops.conv2d_fwd(x, w, 1, 1, 0)
+    with pytest.raises(ValueError):
+        ops.conv2d_fwd(x.float(), w, 1, 1, 0)

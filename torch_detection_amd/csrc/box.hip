@@ -30,11 +30,11 @@ __global__ void anchor_grid_kernel(const float* __restrict__ base, int A, int fe
 
 extern "C" int tdn_anchor_grid(const float* base_anchors, int A, int featH, int featW, int stride, int valid_h,
                                int valid_w, float* anchors, uint8_t* valid, void* stream) {
-  TDN_CHECK(base_anchors && anchors, "tdn_anchor_grid: NULL pointer");
   TDN_CHECK(A > 0 && featH >= 0 && featW >= 0 && stride > 0, "tdn_anchor_grid: bad shape");
   const int64_t total = (int64_t)featH * featW * A;
   TDN_CHECK(total < (1ll << 30), "tdn_anchor_grid: too many anchors");
   if (total == 0) return 0;
+  TDN_CHECK(base_anchors && anchors, "tdn_anchor_grid: NULL pointer");
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(anchor_grid_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, base_anchors, A, featH,

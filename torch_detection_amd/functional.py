@@ -1,0 +1,433 @@
+"""Fused forward/backward schedules of the hot path as ``torch.autograd.Function``s over the HIP kernels.
+
+One Function covers a whole module (all of ResNet, all of FPN, or a single block / ConvModule when those are
+called on their own).  Inside a Function the backward is written out explicitly so that everything the
+reference leaves to autograd as separate passes is fused into GEMM epilogues:
+
+  forward   conv -> BN(eval, folded) -> (+ residual | + nearest-2x upsample) -> ReLU       one kernel
+  backward  dgrad -> (+ residual-branch grad | + external grad | + 2x2 sum-pool) -> ReLU mask of the producer
+            wgrad -> split-K reduce -> BN gamma/beta or bias grads                             two kernels
+
+Reference call sites replaced: BasicBlock.forward resnet.py:42-59, Bottleneck.forward resnet.py:97-119,
+ResNet.forward resnet.py:253-268, ConvModule.forward layers.py:122-135, FPN.forward fpn.py:88-125.
+BN is folded as the per-channel affine the reference's default ``bn_eval=True`` makes it (resnet.py:270-276);
+its gamma/beta still get gradients (``bn_frozen=False``).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ADD_NONE, ADD_SAME, ADD_SUMPOOL2, ADD_UP2X
+
+
+# ---------------------------------------------------------------------------------------------------
+# prepared conv units (packed weights + folded affine), cached per module and refreshed by version
+# ---------------------------------------------------------------------------------------------------
+class ConvUnit(object):
+    """One conv (+BN | +bias) of the reference, prepared for the GEMM kernels."""
+
+    def __init__(self, conv, bn, relu=False):
+        if not isinstance(conv, nn.Conv2d):
+            raise TypeError('expected nn.Conv2d, got %s' % type(conv))
+        kh, kw = conv.kernel_size
+        self.conv, self.bn, self.relu = conv, bn, relu
+        self.k, self.stride, self.pad = kh, conv.stride[0], conv.padding[0]
+        self.Cin, self.Cout = conv.in_channels, conv.out_channels
+        self.is_stem = (kh == 7)
+        if conv.groups != 1:
+            raise NotImplementedError('grouped convolution is not on the HIP path (ResNeXt: SURVEY §2 row 10)')
+        if conv.dilation != (1, 1):
+            raise NotImplementedError('dilated convolution is not on the HIP path yet')
+        if kh != kw or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
+            raise NotImplementedError('only square kernels / strides / paddings are supported')
+        if self.is_stem:
+            if (self.Cin, self.stride, self.pad) != (3, 2, 3) or self.Cout % 64:
+                raise NotImplementedError('7x7 conv is only supported as the ResNet stem (3->64k, stride 2, pad 3)')
+        else:
+            if kh not in (1, 3) or self.stride not in (1, 2) or self.pad != kh // 2:
+                raise NotImplementedError('conv %dx%d stride %d pad %d is not on the HIP path' %
+                                          (kh, kw, self.stride, self.pad))
+            if self.Cin % 64 or self.Cout % 64:
+                raise NotImplementedError('HIP conv path needs channel counts that are multiples of 64 '
+                                          '(got %d -> %d)' % (self.Cin, self.Cout))
+        if bn is not None and not isinstance(bn, nn.BatchNorm2d):
+            raise NotImplementedError('only BatchNorm2d (eval mode) is folded on the HIP path; GroupNorm is '
+                                      'SURVEY §8(f) row 2')
+        self.key = None
+        self.w_fwd = self.w_dgrad = self.scale = self.shift = self.invstd = self.mean = None
+        self.sink = None      # optional (dw, d_affine0, d_affine1) views owned by a gradient bucket (dp.py)
+        self.on_grads = None  # optional callback(unit) fired when this unit's grads have been enqueued
+
+    def params(self):
+        p = [self.conv.weight]
+        if self.bn is not None:
+            p += [self.bn.weight, self.bn.bias]
+        elif self.conv.bias is not None:
+            p.append(self.conv.bias)
+        return p
+
+    def _version_key(self):
+        w = self.conv.weight
+        key = [w.data_ptr(), w._version, w.device]
+        if self.bn is not None:
+            for t in (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var):
+                key += [t.data_ptr(), t._version]
+        elif self.conv.bias is not None:
+            key += [self.conv.bias.data_ptr()]
+        return tuple(key)
+
+    def refresh(self):
+        """(Re)pack weights / fold BN if any source tensor changed since the last call."""
+        if self.bn is not None and self.bn.training:
+            raise NotImplementedError(
+                'BatchNorm2d in training mode (batch statistics) is not on the HIP path; the reference default '
+                'ResNet(bn_eval=True) keeps BN in eval mode (resnet.py:270-276) — call .train()/.eval() on the '
+                'ResNet, or .eval() on this module')
+        w = self.conv.weight
+        if not w.is_cuda:
+            raise RuntimeError('torch_detection_amd modules run on the MI355X HIP path only: move the module to '
+                               'a CUDA/HIP device (no CPU fallback)')
+        key = self._version_key()
+        if key == self.key:
+            return self
+        with torch.no_grad():
+            if w.dtype != torch.float32:
+                raise NotImplementedError('parameters must be float32 (bf16 operands are derived on the fly)')
+            if self.bn is not None:
+                self.scale, self.shift, self.invstd = ops.bn_fold(self.bn.weight, self.bn.bias, self.bn.running_mean,
+                                                                  self.bn.running_var, self.bn.eps)
+                self.mean = self.bn.running_mean
+            else:
+                self.scale = self.invstd = self.mean = None
+                self.shift = self.conv.bias.detach() if self.conv.bias is not None else None
+            if self.is_stem:
+                self.w_fwd = ops.pack_stem_weight(w.detach().contiguous())
+                self.w_dgrad = None
+            else:
+                self.w_fwd, self.w_dgrad = ops.pack_conv_weight(w, self.scale)
+        self.key = key
+        return self
+
+
+def prepare_unit(owner, name, conv, bn, relu=False):
+    """Cached ConvUnit stored on ``owner`` (a module) under ``name``; refreshed if parameters changed."""
+    cache = owner.__dict__.setdefault('_hip_units', {})
+    u = cache.get(name)
+    if u is None or u.conv is not conv or u.bn is not bn:
+        u = ConvUnit(conv, bn, relu)
+        cache[name] = u
+    u.relu = relu
+    return u.refresh()
+
+
+def _hw(t):
+    return (t.shape[1], t.shape[2])
+
+
+def _as_nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def unit_fwd(u, x, addend=None, addend_mode=ADD_NONE, relu=None):
+    return ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode,
+                          u.relu if relu is None else relu)
+
+
+def unit_dgrad(u, g, in_hw, addend=None, addend_mode=ADD_NONE, mask_src=None):
+    if addend is None:
+        addend_mode = ADD_NONE
+    return ops.conv2d_dgrad(g, u.w_dgrad, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
+
+
+def unit_wgrad(u, x_in, g, img_hw=None):
+    """Gradients aligned with ``u.params()``.  With a gradient sink attached (dp.py) the kernels write straight
+    into the bucket views and ``None`` is returned for autograd (``param.grad`` already aliases the views)."""
+    sink = u.sink
+    dw = dg = db = None
+    if sink is not None:
+        dw, d0, d1 = sink
+        if u.bn is not None:
+            dg, db = d0, d1
+        else:
+            db = d0
+    if u.is_stem:
+        dw, dg, db = ops.stem_conv_wgrad(x_in, g, u.w_fwd, img_hw, u.scale, u.mean, u.invstd, dw, dg, db)
+        dw_view = dw
+    else:
+        dw4 = dw.view(u.Cout, u.k, u.k, u.Cin) if dw is not None else None
+        dw4, dg, db = ops.conv2d_wgrad(x_in, g, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.mean, u.invstd, dw4, dg, db)
+        dw_view = dw4.permute(0, 3, 1, 2)
+    if u.on_grads is not None:
+        u.on_grads(u)
+    if sink is not None:
+        return [None] * len(u.params())
+    if u.bn is not None:
+        return [dw_view, dg, db]
+    if u.conv.bias is not None:
+        return [dw_view, db]
+    return [dw_view]
+
+
+# ---------------------------------------------------------------------------------------------------
+# single ConvModule
+# ---------------------------------------------------------------------------------------------------
+class ConvUnitFunction(torch.autograd.Function):
+    """ConvModule.forward (layers.py:122-135) for conv(+bias | +BN eval)(+ReLU)."""
+
+    @staticmethod
+    def forward(ctx, unit, x, *params):
+        xh = ops.to_nhwc_bf16(x)
+        y = unit_fwd(unit, xh)
+        ctx.unit, ctx.xh, ctx.y = unit, xh, y
+        return _as_nchw(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        u = ctx.unit
+        g = ops.to_nhwc_bf16(dy)
+        if u.relu:
+            g = ops.add_relu_mask(g, None, ctx.y)
+        grads = unit_wgrad(u, ctx.xh, g)
+        dx = _as_nchw(unit_dgrad(u, g, _hw(ctx.xh))) if ctx.needs_input_grad[1] else None
+        return (None, dx) + tuple(grads)
+
+
+# ---------------------------------------------------------------------------------------------------
+# residual blocks / ResNet
+# ---------------------------------------------------------------------------------------------------
+class BlockSpec(object):
+    """Prepared BasicBlock (u3 is None) or Bottleneck of the reference (resnet.py:9-119)."""
+
+    def __init__(self, kind, u1, u2, u3, ud, stride):
+        self.kind, self.u1, self.u2, self.u3, self.ud, self.stride = kind, u1, u2, u3, ud, stride
+
+    def units(self):
+        return [u for u in (self.u1, self.u2, self.u3, self.ud) if u is not None]
+
+
+class SeqNet(object):
+    """Prepared straight-line program: optional stem, residual blocks, and which block outputs are returned."""
+
+    def __init__(self, stem, blocks, out_blocks):
+        self.stem, self.blocks, self.out_blocks = stem, blocks, list(out_blocks)
+
+    def units(self):
+        us = [self.stem] if self.stem is not None else []
+        for b in self.blocks:
+            us += b.units()
+        return us
+
+    def params(self):
+        ps = []
+        for u in self.units():
+            ps += u.params()
+        return ps
+
+
+def _block_fwd(x, b):
+    if b.kind == 'bottleneck':
+        h1 = unit_fwd(b.u1, x, relu=True)
+        h2 = unit_fwd(b.u2, h1, relu=True)
+        res = x if b.ud is None else unit_fwd(b.ud, x, relu=False)
+        out = unit_fwd(b.u3, h2, res, ADD_SAME, True)
+        return out, (x, h1, h2, out)
+    h1 = unit_fwd(b.u1, x, relu=True)
+    res = x if b.ud is None else unit_fwd(b.ud, x, relu=False)
+    out = unit_fwd(b.u2, h1, res, ADD_SAME, True)
+    return out, (x, h1, None, out)
+
+
+def _block_bwd(b, saved, g, extra, mask_src, need_dx):
+    """g: gradient w.r.t. the block's pre-ReLU output, already masked by (out > 0).
+    extra: external gradient w.r.t. the block INPUT to fold in (e.g. the FPN's gradient of a stage output).
+    mask_src: if given, the returned dx is masked by (mask_src > 0) — i.e. it already is the masked ``g`` of the
+    block that produced this block's input.  Returns (dx | None, {unit: grads})."""
+    x, h1, h2, out = saved
+    grads = {}
+    if b.kind == 'bottleneck':
+        grads[b.u3] = unit_wgrad(b.u3, h2, g)
+        g2 = unit_dgrad(b.u3, g, _hw(h2), mask_src=h2)
+        grads[b.u2] = unit_wgrad(b.u2, h1, g2)
+        g1 = unit_dgrad(b.u2, g2, _hw(h1), mask_src=h1)
+    else:
+        grads[b.u2] = unit_wgrad(b.u2, h1, g)
+        g1 = unit_dgrad(b.u2, g, _hw(h1), mask_src=h1)
+    grads[b.u1] = unit_wgrad(b.u1, x, g1)
+    if b.ud is not None:
+        grads[b.ud] = unit_wgrad(b.ud, x, g)
+    dx = None
+    if need_dx:
+        if b.ud is not None:
+            t = unit_dgrad(b.ud, g, _hw(x), extra, ADD_SAME)
+        elif extra is not None:
+            t = ops.add_relu_mask(g, extra, None)
+        else:
+            t = g
+        dx = unit_dgrad(b.u1, g1, _hw(x), t, ADD_SAME, mask_src)
+    return dx, grads
+
+
+class SeqNetFunction(torch.autograd.Function):
+    """ResNet.forward (resnet.py:253-268) — or a single residual block — as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        st = {}
+        if net.stem is not None:
+            if x.dim() != 4 or x.shape[1] != 3:
+                raise RuntimeError('ResNet expects an (N,3,H,W) image batch, got %s' % (tuple(x.shape),))
+            img = x if x.dtype == torch.float32 else x.float()
+            H, W = img.shape[2], img.shape[3]
+            xp = ops.stage_image(img)
+            s = ops.stem_conv_fwd(xp, net.stem.w_fwd, (H, W), net.stem.scale, net.stem.shift, True)
+            cur, idx = ops.maxpool3x3s2_fwd(s)
+            st.update(xp=xp, s=s, idx=idx, img_hw=(H, W))
+        else:
+            cur = ops.to_nhwc_bf16(x)
+        saved, outs = [], []
+        for bi, b in enumerate(net.blocks):
+            cur, sv = _block_fwd(cur, b)
+            saved.append(sv)
+            if bi in net.out_blocks:
+                outs.append(cur)
+        if not net.blocks:
+            outs.append(cur)
+        ctx.net, ctx.st, ctx.saved = net, st, saved
+        return tuple(_as_nchw(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        net, st, saved = ctx.net, ctx.st, ctx.saved
+        ext = {}
+        for bi, d in zip(net.out_blocks, douts):
+            if d is not None:
+                ext[bi] = ops.to_nhwc_bf16(d)
+        unit_grads = {}
+        need_net_dx = ctx.needs_input_grad[1] and net.stem is None
+        g = None
+        for bi in reversed(range(len(net.blocks))):
+            b, sv = net.blocks[bi], saved[bi]
+            if g is None:
+                e = ext.get(bi)
+                if e is None:
+                    continue  # nothing flows into this block's output
+                g = ops.add_relu_mask(e, None, sv[3])
+            extra = ext.get(bi - 1) if bi > 0 else None
+            mask_src = saved[bi - 1][3] if bi > 0 else None
+            need_dx = bi > 0 or net.stem is not None or need_net_dx
+            g, gr = _block_bwd(b, sv, g, extra, mask_src, need_dx)
+            unit_grads.update(gr)
+        dx_in = None
+        if net.stem is not None:
+            if g is not None:
+                H, W = st['img_hw']
+                ds = ops.maxpool3x3s2_bwd(g, st['idx'], (H // 2, W // 2), st['s'])
+                unit_grads[net.stem] = unit_wgrad(net.stem, st['xp'], ds, (H, W))
+            # the image itself gets no gradient (the reference never needs one; SURVEY §8(d): -5.06 GFLOP)
+        elif need_net_dx and g is not None:
+            dx_in = _as_nchw(g)
+        flat = []
+        for u in net.units():
+            flat += unit_grads.get(u, [None] * len(u.params()))
+        return (None, dx_in) + tuple(flat)
+
+
+# ---------------------------------------------------------------------------------------------------
+# FPN
+# ---------------------------------------------------------------------------------------------------
+class FPNNet(object):
+    def __init__(self, lat, fpn, start_level, backbone_end_level, num_outs, add_extra_convs, num_ins):
+        self.lat, self.fpn = lat, fpn
+        self.start_level, self.backbone_end_level = start_level, backbone_end_level
+        self.num_outs, self.add_extra_convs, self.num_ins = num_outs, add_extra_convs, num_ins
+
+    def units(self):
+        return list(self.lat) + list(self.fpn)
+
+    def params(self):
+        ps = []
+        for u in self.units():
+            ps += u.params()
+        return ps
+
+
+class FPNFunction(torch.autograd.Function):
+    """FPN.forward (fpn.py:88-125): laterals, top-down nearest-2x add (fused into the lateral epilogue),
+    3x3 output convs, extra levels by stride-2 subsampling (fpn.py:114-116) or stride-2 convs (fpn.py:118-124)."""
+
+    @staticmethod
+    def forward(ctx, net, *args):
+        inputs = args[:net.num_ins]
+        nlat = len(net.lat)
+        xs = [ops.to_nhwc_bf16(inputs[i + net.start_level]) for i in range(nlat)]
+        lat = [None] * nlat
+        for i in reversed(range(nlat)):
+            if i == nlat - 1:
+                lat[i] = unit_fwd(net.lat[i], xs[i])
+            else:
+                lat[i] = unit_fwd(net.lat[i], xs[i], lat[i + 1], ADD_UP2X)
+        outs = [unit_fwd(net.fpn[i], lat[i]) for i in range(nlat)]
+        extra_in = []   # inputs of the extra stride-2 convs (RetinaNet style), for backward
+        if net.num_outs > nlat:
+            if not net.add_extra_convs:
+                for _ in range(net.num_outs - nlat):
+                    outs.append(ops.subsample2_fwd(outs[-1]))
+            else:
+                orig = ops.to_nhwc_bf16(inputs[net.backbone_end_level - 1])
+                outs.append(unit_fwd(net.fpn[nlat], orig))
+                extra_in.append(orig)
+                for i in range(nlat + 1, net.num_outs):
+                    # F.relu(outs[-1], inplace=True) in the reference also rewrites the returned level (fpn.py:124)
+                    outs[-1] = ops.add_relu_mask(outs[-1], None, outs[-1])
+                    outs.append(unit_fwd(net.fpn[i], outs[-1]))
+                    extra_in.append(outs[-2])
+        ctx.net, ctx.xs, ctx.lat, ctx.extra_in = net, xs, lat, extra_in
+        ctx.out_hw = [_hw(o) for o in outs]
+        ctx.out_meta = (outs[0].shape[0], outs[0].shape[3], outs[0].device)
+        return tuple(_as_nchw(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        net, xs, lat = ctx.net, ctx.xs, ctx.lat
+        nlat = len(net.lat)
+        N, C, dev = ctx.out_meta
+        d = [ops.to_nhwc_bf16(t) if t is not None else None for t in douts]
+
+        def zeros(i):
+            h, w = ctx.out_hw[i]
+            return torch.zeros(N, h, w, C, dtype=ops.BF16, device=dev)
+
+        unit_grads = {}
+        dx = [None] * net.num_ins
+        if net.num_outs > nlat:
+            if not net.add_extra_convs:
+                for j in range(net.num_outs - 1, nlat - 1, -1):
+                    if d[j] is not None:
+                        d[j - 1] = ops.subsample2_bwd(d[j], ctx.out_hw[j - 1], d[j - 1])
+            else:
+                for j in range(net.num_outs - 1, nlat - 1, -1):
+                    gj = d[j] if d[j] is not None else zeros(j)
+                    xin = ctx.extra_in[j - nlat]
+                    unit_grads[net.fpn[j]] = unit_wgrad(net.fpn[j], xin, gj)
+                    if j > nlat:
+                        # input was relu(out[j-1]) written back in place: mask by the (ReLU'd) saved tensor
+                        d[j - 1] = unit_dgrad(net.fpn[j], gj, _hw(xin), d[j - 1], ADD_SAME, xin)
+                    else:
+                        k = net.backbone_end_level - 1
+                        if ctx.needs_input_grad[1 + k]:
+                            dx[k] = unit_dgrad(net.fpn[j], gj, _hw(xin))
+        dL = [None] * nlat
+        for i in range(nlat):
+            gi = d[i] if d[i] is not None else zeros(i)
+            unit_grads[net.fpn[i]] = unit_wgrad(net.fpn[i], lat[i], gi)
+            dL[i] = unit_dgrad(net.fpn[i], gi, _hw(lat[i]), dL[i - 1] if i > 0 else None, ADD_SUMPOOL2)
+        for i in range(nlat):
+            unit_grads[net.lat[i]] = unit_wgrad(net.lat[i], xs[i], dL[i])
+            k = i + net.start_level
+            if ctx.needs_input_grad[1 + k]:
+                t = unit_dgrad(net.lat[i], dL[i], _hw(xs[i]), dx[k], ADD_SAME)
+                dx[k] = t
+        flat = []
+        for u in net.units():
+            flat += unit_grads.get(u, [None] * len(u.params()))
+        return (None,) + tuple(_as_nchw(t) if t is not None else None for t in dx) + tuple(flat)
