@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of ResNet-50-FPN forward+backward at "1333x800" (zero-padded to 800x1344) on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL); this file reads
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
+One step = one pass of the hot path over one synthetic batch: stage image -> ResNet-50 -> FPN (5 levels)
+forward, backward from fixed cotangents g_l = randn_like(P_l)/numel(P_l) (the reference has no head / loss,
+SURVEY §8(d) C4), all parameter gradients (conv weights, BN gamma/beta, FPN biases), and for N > 1 the bucketed
+RCCL all-reduce of the 26.85 M gradients overlapped with backward.  Weak scaling: 2 images per GPU.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+H_PAD, W_PAD = 800, 1344           # "1333x800" padded to a multiple of 32 (image.py:326-347)
+FWD_GFLOP = {50: 296.96, 101: 456.06}     # per image, SURVEY §8(d)
+FWDBWD_GFLOP = {50: 885.8, 101: 1363.1}   # 3*fwd - dgrad(conv1)
+MFMA_PEAK_TFLOPS = 2500.0          # bf16 dense, MI355X_MICROARCH.md
+DOM = dict(Cin=256, Cout=256, k=3, stride=1, H=200, W=336)   # neck.fpn_convs.0: 79.27 GFLOP / image
+
+
+def build_models(depth, device, seed=0):
+    import torch_detection_amd as T
+    torch.manual_seed(seed)
+    backbone = T.BACKBONES.module_dict["ResNet"](depth)
+    neck = T.NECKS.module_dict["FPN"]([256, 512, 1024, 2048], 256, 5)
+    backbone.init_weights()
+    neck.init_weights()
+    g = torch.Generator().manual_seed(1)
+    for m in backbone.modules():          # non-trivial BN statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    backbone.to(device).train()
+    neck.to(device).train()
+    return backbone, neck
+
+
+class KernelTimer(object):
+    """HIP-event timing of ONE kernel launch shape (the dominant conv) on the stream it is launched on."""
+
+    def __init__(self, ops, match):
+        self.ops, self.match, self.pairs = ops, match, []
+        self._orig = ops.conv2d_fwd
+
+    def __enter__(self):
+        orig, match, pairs = self._orig, self.match, self.pairs
+
+        def timed(x, w_fwd, k, stride, pad, *a, **kw):
+            hit = (tuple(x.shape[1:]) == (match["H"], match["W"], match["Cin"]) and w_fwd.shape[0] == match["Cout"]
+                   and k == match["k"] and stride == match["stride"])
+            if not hit:
+                return orig(x, w_fwd, k, stride, pad, *a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig(x, w_fwd, k, stride, pad, *a, **kw)
+            e1.record()
+            pairs.append((e0, e1, x.shape[0]))
+            return y
+        self.ops.conv2d_fwd = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.conv2d_fwd = self._orig
+
+    def summary(self):
+        if not self.pairs:
+            return None
+        ms = [a.elapsed_time(b) for a, b, _ in self.pairs]
+        n = self.pairs[0][2]
+        return sum(ms) / len(ms), n, len(ms)
+
+
+def cpu_baseline(depth, iters=2):
+    """The CPU oracle (restatement of the reference's PyTorch-CPU path, bit-equal to it: oracle/gen_golden.py)
+    timed on this host's cores on a bounded sample: `iters` fwd+bwd passes of ONE 3x800x1344 image."""
+    from golden_util import det_tensor
+    from oracle import torch_ref as O
+    import torch_detection_amd as T
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    rb, rf = T.ResNet(depth), T.FPN([256, 512, 1024, 2048], 256, 5)
+    rb.init_weights()
+    rf.init_weights()
+    sdb, sdf = rb.state_dict(), rf.state_dict()
+    x = det_tensor((1, 3, H_PAD, W_PAD), 1, -2, 2)
+    sizes = [(H_PAD // s, W_PAD // s) for s in (4, 8, 16, 32)] + [((H_PAD // 32 + 1) // 2, (W_PAD // 32 + 1) // 2)]
+    cots = [torch.randn(1, 256, h, w) / (256 * h * w) for h, w in sizes]
+    times = []
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        O.resnet_fpn_fwd_bwd(sdb, sdf, x, depth, cots)
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": round(1.0 / best, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d timed fwd+bwd passes (after 1 warm-up) of one 3x%dx%d image through oracle/torch_ref.py "
+                      "(R%d-FPN, fp32, torch CPU, %d threads); best %.2f s" % (iters, H_PAD, W_PAD, depth, cores, best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--batch-per-gpu", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--bucket-mb", type=int, default=32)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
+                             "(--nproc-per-node %d)" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from torch_detection_amd import dp, ops
+    backbone, neck = build_models(args.depth, device)
+    if world > 1:   # identical weights everywhere: broadcast rank 0's
+        for p in list(backbone.state_dict().values()) + list(neck.state_dict().values()):
+            dist.broadcast(p, 0)
+    B = args.batch_per_gpu
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    x = torch.zeros(B, 3, H_PAD, W_PAD)
+    x[:, :, :, :1333] = torch.randn(B, 3, H_PAD, 1333, generator=g)   # logical 800x1333, zero right pad
+    x = x.to(device)
+    with torch.no_grad():
+        outs = neck(backbone(x))
+    g2 = torch.Generator(device="cpu").manual_seed(2)
+    cots = [(torch.randn(o.shape, generator=g2) / o[0].numel()).to(device=device, dtype=o.dtype) for o in outs]
+    del outs
+
+    reducer = dp.attach_reducer([neck, backbone], bucket_bytes=args.bucket_mb << 20) if world > 1 else None
+    params = list(backbone.parameters()) + list(neck.parameters())
+
+    def step():
+        if reducer is None:
+            for p in params:
+                p.grad = None
+        outs = neck(backbone(x))
+        torch.autograd.backward(outs, cots)
+        if reducer is not None:
+            reducer.finish()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = None if args.no_kernel_timer else KernelTimer(ops, DOM)
+    sync()
+    t0 = time.perf_counter()
+    if timer is not None:
+        with timer:
+            for _ in range(args.steps):
+                step()
+            sync()
+            elapsed = time.perf_counter() - t0
+    else:
+        for _ in range(args.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        imgs = B * world * args.steps
+        value = imgs / elapsed
+        mfma_frac = value * FWDBWD_GFLOP[args.depth] / 1e3 / (world * MFMA_PEAK_TFLOPS)
+        roof = None
+        if timer is not None and timer.summary():
+            ms, nimg, cnt = timer.summary()
+            flop = 2.0 * nimg * DOM["H"] * DOM["W"] * DOM["Cout"] * DOM["Cin"] * DOM["k"] ** 2
+            ach = flop / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv_gemm_kernel<128,128,64> @ neck.fpn_convs.0 fwd (M=%d,N=256,K=2304)" %
+                              (nimg * DOM["H"] * DOM["W"]),
+                    "avg_ms": round(ms, 4), "launches_timed": cnt}
+        line = {
+            "metric": "images/sec ResNet-50-FPN fwd+bwd 1333x800" if args.depth == 50 else
+                      "images/sec ResNet-%d-FPN fwd+bwd 1333x800" % args.depth,
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ResNet-%d + FPN(256, 5 levels) forward+backward, %d x 3x800x1344 "
+                                   "(1333x800 zero-padded to /32) per GPU, BN eval (reference default), fixed "
+                                   "cotangents, all parameter grads%s" %
+                                   (args.depth, B, ", bucketed RCCL all-reduce (sum/%d) overlapped with backward"
+                                    % world if world > 1 else ""),
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "mfma_frac_whole_step": round(mfma_frac, 4),
+                       "algorithmic_gflop_per_image": FWDBWD_GFLOP[args.depth]},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.depth)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

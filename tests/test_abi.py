@@ -1,0 +1,54 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tdn.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "tdn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tdn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from torch_detection_amd import _lib
+    names = _declared()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libtdn.so does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names, set(names) ^ set(_lib.SIGNATURES)
+    assert _lib.load().tdn_version() == 100
+
+
+def test_epilogue_struct_layout():
+    from torch_detection_amd._lib import Epilogue
+    # mirror of tdn_epilogue: 3 pointers, 4 int32, pointer, 2 int32 (LP64)
+    assert ctypes.sizeof(Epilogue) == 56
+    assert Epilogue.mask_src.offset == 40 and Epilogue.out_f32.offset == 48
+
+
+def test_host_side_plans_and_errors():
+    """tdn_conv2d_plan is host-only: GEMM decomposition of the BASELINE shapes."""
+    from torch_detection_amd import _lib
+    lib = _lib.load()
+    o = (ctypes.c_int32 * 16)()
+    # neck.fpn_convs.0 forward, B=2: M=134400, N=256, K=2304
+    assert lib.tdn_conv2d_plan(0, 2, 200, 336, 256, 256, 3, 1, 1, o) == 0
+    assert (o[0], o[1], o[2]) == (134400, 256, 2304) and o[9] == 1 and o[10] == 9
+    # stride-2 3x3 dgrad: 4 output-parity classes with 1+2+2+4 = 9 taps, all H*W pixels covered once
+    assert lib.tdn_conv2d_plan(1, 2, 25, 42, 512, 512, 3, 2, 1, o) == 0
+    assert o[9] == 4 and o[12] == 9 and o[0] == 2 * 25 * 42
+    # 1x1 stride-2 dgrad: only the even/even class has a tap
+    assert lib.tdn_conv2d_plan(1, 1, 50, 84, 512, 1024, 1, 2, 0, o) == 0
+    assert o[9] == 4 and o[12] == 1 and o[10] == 1
+    # wgrad: split-K over pixels
+    assert lib.tdn_conv2d_plan(2, 2, 200, 336, 256, 256, 3, 1, 1, o) == 0
+    assert (o[0], o[1], o[2]) == (256, 2304, 134400) and o[11] >= 8 and o[12] % 64 == 0
+    assert o[11] * o[12] >= 134400
+    # errors are reported, not thrown
+    assert lib.tdn_conv2d_plan(0, 2, 25, 42, 500, 512, 3, 2, 1, o) != 0
+    assert b"multiples of 64" in lib.tdn_last_error()
+    assert lib.tdn_conv2d_plan(0, 1, 8, 8, 64, 64, 5, 1, 2, o) != 0

@@ -1,0 +1,91 @@
+"""CPU, world_size = 2 over gloo: the bucketed flat-buffer gradient exchange (torch_detection_amd/dp.py) gives every
+rank the same result as a single process on the concatenated batch (sum over images / world).  The per-rank
+gradients come from the CPU oracle; on the GPU box the same GradReducer is driven by the HIP backward
+(functional.unit_wgrad sinks) with RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from golden_util import det_tensor, fill_state_dict, rel_l2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _grads(sdb, sdf, x, cots):
+    from oracle import torch_ref as O
+    _, g = O.resnet_fpn_fwd_bwd(sdb, sdf, x, 18, cots)
+    return g
+
+
+def _worker(rank, world, port, bucket_bytes, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import torch_detection_amd as T
+    from torch_detection_amd import dp
+    sdb = fill_state_dict(T.ResNet(18).state_dict(), 50)
+    sdf = fill_state_dict(T.FPN([64, 128, 256, 512], 256, 5).state_dict(), 51)
+    xall = det_tensor((world, 3, 64, 64), 900, -2, 2)
+    shapes = [(1, 256, 16, 16), (1, 256, 8, 8), (1, 256, 4, 4), (1, 256, 2, 2), (1, 256, 1, 1)]
+    sl = dp.shard_for_rank(world, rank, world)
+    cots = [det_tensor(s, 910 + i, -1, 1) for i, s in enumerate(shapes)]
+    g = _grads(sdb, sdf, xall[sl], cots)
+    names = sorted(g)[::-1]          # any fixed "ready" order
+    red = dp.GradReducer([g[k].numel() for k in names], "cpu", bucket_bytes=bucket_bytes)
+    assert len(red.buckets) > 1
+    for step in range(2):            # two steps: the reducer re-arms itself
+        for i, k in enumerate(names):
+            red.views[i].copy_(g[k].reshape(-1))
+            red.mark_ready(i)
+        red.finish()
+    torch.save({k: red.views[i].clone().view(g[k].shape) for i, k in enumerate(names)},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [1 << 20, 8 << 20])
+def test_two_rank_average_equals_single_process(tmp_path, bucket_bytes):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), bucket_bytes, str(tmp_path)), nprocs=world, join=True)
+    import torch_detection_amd as T
+    sdb = fill_state_dict(T.ResNet(18).state_dict(), 50)
+    sdf = fill_state_dict(T.FPN([64, 128, 256, 512], 256, 5).state_dict(), 51)
+    xall = det_tensor((world, 3, 64, 64), 900, -2, 2)
+    shapes = [(1, 256, 16, 16), (1, 256, 8, 8), (1, 256, 4, 4), (1, 256, 2, 2), (1, 256, 1, 1)]
+    cots = [det_tensor(s, 910 + i, -1, 1).expand(world, -1, -1, -1).contiguous() for i, s in enumerate(shapes)]
+    torch.set_num_threads(4)
+    full = _grads(sdb, sdf, xall, cots)
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"), weights_only=True)
+    for k in full:
+        assert torch.equal(r0[k], r1[k]), k                      # every rank holds the same reduced gradient
+        assert rel_l2(r0[k], full[k] / world) <= 1e-5, k         # == single-process gradient / world
+
+
+def test_reducer_bucket_layout():
+    from torch_detection_amd import dp
+    red = dp.GradReducer([10, 100, 1000, 5000, 7], "cpu", bucket_bytes=4096)
+    assert all(o % 64 == 0 for o in red.offsets)
+    assert [v.numel() for v in red.views] == [10, 100, 1000, 5000, 7]
+    assert red.buckets[0][0] == 0 and red.buckets[-1][1] == red.flat.numel()
+    assert sum(b[2] for b in red.buckets) == 5
+    for i in range(5):
+        red.mark_ready(i)
+    red.finish()
+    with pytest.raises(RuntimeError):
+        for _ in range(2):
+            red.mark_ready(0)
+            red.mark_ready(0)
+    assert dp.shard_for_rank(16, 3, 8) == slice(6, 8)

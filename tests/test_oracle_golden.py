@@ -1,0 +1,137 @@
+"""CPU: oracle/torch_ref.py reproduces the golden vectors captured from the reference import bit for bit
+(tests/golden/, written by oracle/gen_golden.py — the only code that imports /root/reference), and the drop-in
+modules expose the reference's state_dict keys, shapes and constructor behaviour."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import det_tensor, fill_state_dict
+
+
+@pytest.fixture(scope="module")
+def manifest(golden_dir):
+    with open(os.path.join(golden_dir, "manifest.json")) as fh:
+        return json.load(fh)
+
+
+def _keys(m):
+    return [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+
+
+def test_state_dict_manifests(manifest):
+    import torch_detection_amd as T
+    for d in (18, 50, 101):
+        assert _keys(T.ResNet(d)) == manifest["resnet%d" % d]
+    assert len(manifest["resnet18"]) == 120 and len(manifest["resnet50"]) == 318 and len(manifest["resnet101"]) == 624
+    assert _keys(T.FPN([256, 512, 1024, 2048], 256, 5)) == manifest["fpn_r50"]
+    assert _keys(T.FPN([64, 128, 256, 512], 256, 5)) == manifest["fpn_r18"]
+    assert len(manifest["fpn_r50"]) == 16
+    assert "ResNet" in manifest["registry"]["backbone"] and "FPN" in manifest["registry"]["neck"]
+    assert "ResNet" in T.BACKBONES.module_dict and "FPN" in T.NECKS.module_dict
+
+
+def test_resnet18_config1_oracle_bit_exact(manifest, golden_dir):
+    """BASELINE config 1: ResNet-18 forward, 1x3x224x224, PyTorch CPU."""
+    import torch_detection_amd as T
+    from oracle import torch_ref as O
+    meta = manifest["resnet18_c1"]
+    gold = np.load(os.path.join(golden_dir, "resnet18_c1.npz"))
+    sd = fill_state_dict(T.ResNet(18).state_dict(), meta["state_seed"])
+    i = meta["input"]
+    x = det_tensor(tuple(i["shape"]), i["seed"], i["lo"], i["hi"])
+    torch.set_num_threads(4)
+    with torch.no_grad():
+        outs = O.resnet_forward(sd, x, 18)
+    for k, o in enumerate(outs):
+        assert np.array_equal(o.numpy(), gold["c%d" % (k + 2)]), k
+
+
+@pytest.mark.parametrize("depth", [50, 101])
+def test_resnet_small_oracle_checksums(manifest, depth):
+    import torch_detection_amd as T
+    from oracle import torch_ref as O
+    meta = manifest["resnet%d_small" % depth]
+    sd = fill_state_dict(T.ResNet(depth).state_dict(), meta["state_seed"])
+    i = meta["input"]
+    x = det_tensor(tuple(i["shape"]), i["seed"], i["lo"], i["hi"])
+    torch.set_num_threads(4)
+    with torch.no_grad():
+        outs = O.resnet_forward(sd, x, depth)
+    assert [float(t.double().sum()) for t in outs] == meta["sum"]
+    assert [float(t.double().abs().sum()) for t in outs] == meta["abssum"]
+
+
+def test_fpn_oracle_bit_exact(manifest, golden_dir):
+    import torch_detection_amd as T
+    from oracle import torch_ref as O
+    meta = manifest["fpn_small"]
+    gold = np.load(os.path.join(golden_dir, "fpn.npz"))
+    sd = fill_state_dict(T.FPN(meta["in_channels"], meta["out_channels"], meta["num_outs"]).state_dict(),
+                         meta["state_seed"])
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ins = [det_tensor((meta["N"], c, h, w), meta["in_seed0"] + i, -1, 1).requires_grad_(True)
+           for i, (c, (h, w)) in enumerate(zip(meta["in_channels"], meta["sizes"]))]
+    outs = O.fpn_forward(ps, ins, meta["num_outs"])
+    cots = [det_tensor(tuple(o.shape), meta["cot_seed0"] + i, -1, 1) for i, o in enumerate(outs)]
+    torch.autograd.backward(outs, cots)
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.detach().numpy(), gold["out%d" % i])
+    for i, t in enumerate(ins):
+        assert np.array_equal(t.grad.numpy(), gold["din%d" % i])
+    for k, p in ps.items():
+        assert np.array_equal(p.grad.numpy(), gold["grad/" + k]), k
+
+
+def test_block_oracle_bit_exact(manifest, golden_dir):
+    from oracle import torch_ref as O
+    import torch_detection_amd as T
+    from torch_detection_amd.backbone.resnet import _make_res_layer
+    gold = np.load(os.path.join(golden_dir, "blocks.npz"))
+    for name, meta in sorted(manifest["blocks"].items()):
+        cls = getattr(T, meta["cls"])
+        blk = _make_res_layer(cls, meta["inplanes"], meta["planes"], 1, stride=meta["stride"])[0]
+        assert _keys(blk) == meta["state_keys"]
+        sd = fill_state_dict(blk.state_dict(), meta["state_seed"])
+        ps = {("b." + k): v.clone().requires_grad_(v.is_floating_point() and "running" not in k)
+              for k, v in sd.items()}
+        x = det_tensor(tuple(meta["x_shape"]), meta["x_seed"], -1, 1).requires_grad_(True)
+        fn = O._basic_block if meta["cls"] == "BasicBlock" else O._bottleneck
+        y = fn(x, ps, "b", meta["stride"], 1, blk.downsample is not None)
+        y.backward(det_tensor(tuple(y.shape), meta["dy_seed"], -1, 1))
+        assert np.array_equal(y.detach().numpy(), gold[name + "/y"]), name
+        assert np.array_equal(x.grad.numpy(), gold[name + "/dx"]), name
+        for k, p in blk.named_parameters():
+            assert np.array_equal(ps["b." + k].grad.numpy(), gold[name + "/grad/" + k]), (name, k)
+
+
+def test_constructor_and_registry_semantics(manifest):
+    import torch_detection_amd as T
+    import torch.nn as nn
+    with pytest.raises(KeyError) as e:
+        T.ResNet(20)
+    assert manifest["bad_depth_error"] == "KeyError:" + str(e.value)
+    with pytest.raises(TypeError) as e:
+        T.ResNet(18).init_weights(pretrained=3)
+    assert manifest["bad_pretrained_error"] == "TypeError:" + str(e.value)
+    reg = T.Registry("x")
+    with pytest.raises(TypeError):
+        reg.register_module(int)
+
+    @reg.register_module
+    class Foo(nn.Module):
+        pass
+    assert reg.module_dict["Foo"] is Foo and reg.name == "x"
+    with pytest.raises(KeyError):
+        reg.register_module(Foo)
+    m = T.ResNet(18)
+    assert m.train() is m and all(not b.training for b in m.modules() if isinstance(b, nn.BatchNorm2d))
+    assert manifest["train_semantics"]["all_bn_eval_after_train"]
+    # the product path has no CPU fallback
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 64, 64))
+    # non-hot-path configurations are constructible (checkpoints stay inspectable) but refuse to run silently
+    g = T.ResNet(18, use_gn=True)
+    assert "gn1.weight" in g.state_dict()

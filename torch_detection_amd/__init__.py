@@ -1,2 +1,17 @@
-"""torch_detection_amd — MI355X-native ResNet/FPN + box-op hot path behind the Torch_Detection registry."""
+"""torch_detection_amd — MI355X-native ResNet/FPN + box-op hot path behind the Torch_Detection registry.
+
+Drop-in surface (same names as the reference's ``models`` package): ``BACKBONES``, ``NECKS``, ``ResNet``,
+``FPN``, ``ConvModule``, the conv/norm builders and init helpers.  Everything computes through libtdn.so
+(hand-written gfx950 HIP kernels, C ABI in include/tdn.h); there is no CPU or eager fallback.
+"""
 __version__ = "0.1.0"
+
+from .registry import BACKBONES, NECKS, Registry  # noqa: F401
+from .layers import (ConvModule, conv1x1_group, conv3x3_group, conv7x7_group, get_group_gn,  # noqa: F401
+                     norm_layer)
+from .inits import (bias_init_with_prob, constant_init, kaiming_init, normal_init, uniform_init,  # noqa: F401
+                    xavier_init)
+from .checkpoint import load_checkpoint, load_state_dict, save_checkpoint  # noqa: F401
+from .backbone import BasicBlock, Bottleneck, ResNet  # noqa: F401
+from .necks import FPN  # noqa: F401
+from .box import AnchorGenerator, bbox_overlaps, nms, nms_mask  # noqa: F401

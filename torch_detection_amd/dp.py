@@ -1,0 +1,152 @@
+"""Data-parallel gradient exchange: one process per GPU, bucketed all-reduce (RCCL over xGMI) overlapped with
+backward on a side HIP stream.
+
+The reference contains no communication at all (only ``dist.get_world_size()/get_rank()`` in
+datasets/loader/dataset_sampler.py:98,103); what it does fix is the sharding model — one process per GPU,
+each rank takes its own ``samples_per_gpu`` slice (dataset_sampler.py:169-172, build_dataloader.py:27-30) and,
+because BN runs on running statistics (resnet.py:270-276), the only exchange per step is the parameter
+gradient sum.  This module supplies that exchange:
+
+  * all gradients live in ONE flat fp32 buffer laid out in the order the backward pass finishes them
+    (FPN -> layer4 -> ... -> stem); the weight-gradient kernels write straight into it (functional.unit_wgrad
+    ``sink``), ``param.grad`` are views — no flatten / unflatten copies;
+  * the buffer is cut into buckets of ``bucket_bytes``; when the last gradient of a bucket has been enqueued,
+    an event is recorded on the compute stream, the comm stream waits on it and issues ``all_reduce`` for that
+    bucket — RCCL then runs concurrently with the rest of backward;
+  * xGMI is point-to-point (7 links x ~153 GB/s per GPU), so buckets are kept large (default 32 MiB: 4 buckets
+    for R50-FPN's 107 MB) and RCCL is left to spread rings/channels over all links;
+  * ``finish()`` makes the compute stream wait for the comm stream and applies the 1/world average.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer(object):
+    """Flat-buffer bucketed all-reduce.  ``numels``: gradient sizes in the order they become ready."""
+
+    def __init__(self, numels, device, bucket_bytes=32 << 20, group=None, average=True, dtype=torch.float32):
+        self.device = torch.device(device)
+        self.group = group
+        self.average = average
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # 64-element (256 B) alignment of every slot keeps kernels' float4 stores aligned
+        self.offsets, off = [], 0
+        for n in numels:
+            self.offsets.append(off)
+            off += (int(n) + 63) // 64 * 64
+        self.numels = [int(n) for n in numels]
+        self.flat = torch.zeros(max(off, 64), dtype=dtype, device=self.device)
+        self.views = [self.flat[o:o + n] for o, n in zip(self.offsets, self.numels)]
+        esize = self.flat.element_size()
+        # buckets: consecutive slots, closed when they reach bucket_bytes
+        self.bucket_of, self.buckets = [], []   # buckets: [start_off, end_off, nslots]
+        cur_start, cur_slots = 0, 0
+        for i, (o, n) in enumerate(zip(self.offsets, self.numels)):
+            self.bucket_of.append(len(self.buckets))
+            cur_slots += 1
+            end = o + (n + 63) // 64 * 64
+            if (end - cur_start) * esize >= bucket_bytes or i == len(self.numels) - 1:
+                self.buckets.append([cur_start, end, cur_slots])
+                cur_start, cur_slots = end, 0
+        self.use_streams = self.device.type == 'cuda'
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_streams else None
+        self._pending = None
+        self._works = []
+        self.reset()
+
+    def reset(self):
+        self._pending = [b[2] for b in self.buckets]
+        self._works = []
+
+    def mark_ready(self, slot):
+        """Slot's gradient has been enqueued on the current stream; launch its bucket's all-reduce if complete."""
+        b = self.bucket_of[slot]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+        elif self._pending[b] < 0:
+            raise RuntimeError('GradReducer: slot %d marked ready twice in one step (call reset()/finish())' % slot)
+
+    def _launch(self, b):
+        start, end, _ = self.buckets[b]
+        buf = self.flat[start:end]
+        if self.world == 1:
+            return
+        if self.use_streams:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(w)
+
+    def finish(self):
+        """Wait for every bucket (compute stream waits on the comm stream), average, and re-arm."""
+        missing = [i for i, p in enumerate(self._pending) if p > 0]
+        if missing:
+            # gradients that were never produced this step (e.g. frozen stages): reduce what is there
+            for b in missing:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        if self.use_streams and self.world > 1:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        if self.average and self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+        self.reset()
+
+
+def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True):
+    """Wire ``GradReducer`` into HIP-path modules (given in the order their backward runs, e.g. [fpn, resnet]).
+
+    Every conv unit's weight/affine gradients get a slot in the flat buffer (in backward-completion order),
+    ``param.grad`` is pre-assigned to the slot view, and the unit reports readiness to the reducer from inside
+    the backward schedule.  Returns the reducer; call ``reducer.finish()`` after ``backward()``.
+    """
+    units = []
+    for m in modules:
+        net = m.hip_net()
+        us = net.units()
+        # FPN finishes fpn_convs then laterals; SeqNet finishes last block first, stem last
+        order = list(us) if hasattr(net, 'lat') else list(reversed(us))
+        if hasattr(net, 'lat'):
+            order = list(net.fpn) + list(net.lat)
+        units += order
+    numels, owners = [], []
+    for u in units:
+        for p in u.params():
+            numels.append(p.numel())
+            owners.append((u, p))
+    dev = units[0].conv.weight.device
+    red = GradReducer(numels, dev, bucket_bytes, group, average)
+    slot = 0
+    for u in units:
+        ps = u.params()
+        views = red.views[slot:slot + len(ps)]
+        slots = list(range(slot, slot + len(ps)))
+        slot += len(ps)
+        w = ps[0]
+        if u.is_stem:
+            wview = views[0].view(w.shape)
+        else:
+            wview = views[0].view(u.Cout, u.k, u.k, u.Cin).permute(0, 3, 1, 2)
+        w.grad = wview
+        for p, v in zip(ps[1:], views[1:]):
+            p.grad = v.view(p.shape)
+        u.sink = (views[0].view(w.shape) if u.is_stem else views[0], views[1] if len(ps) > 1 else None,
+                  views[2] if len(ps) > 2 else None)
+
+        def _cb(unit, _slots=slots, _red=red):
+            for s in _slots:
+                _red.mark_ready(s)
+        u.on_grads = _cb
+    return red
+
+
+def shard_for_rank(num_samples, rank, world):
+    """Rank-contiguous slice of a batch, the sharding rule of DistributedGroupSampler
+    (dataset_sampler.py:169-172): rank r takes samples [r*n, (r+1)*n)."""
+    n = num_samples // world
+    return slice(rank * n, (rank + 1) * n)

@@ -19,6 +19,10 @@ import torch.nn as nn
 from . import ops
 from .ops import ADD_NONE, ADD_SAME, ADD_SUMPOOL2, ADD_UP2X
 
+# Test instrumentation: when set to a dict, the forward passes drop references to the tensors they save for
+# backward into it (keys 'seq', 'fpn') so parity tests can teacher-force the CPU schedule oracle with them.
+DEBUG_CAPTURE = None
+
 
 # ---------------------------------------------------------------------------------------------------
 # prepared conv units (packed weights + folded affine), cached per module and refreshed by version
@@ -293,6 +297,8 @@ class SeqNetFunction(torch.autograd.Function):
         if not net.blocks:
             outs.append(cur)
         ctx.net, ctx.st, ctx.saved = net, st, saved
+        if DEBUG_CAPTURE is not None:
+            DEBUG_CAPTURE['seq'] = (st, saved)
         return tuple(_as_nchw(o) for o in outs)
 
     @staticmethod
@@ -382,6 +388,8 @@ class FPNFunction(torch.autograd.Function):
                     outs.append(unit_fwd(net.fpn[i], outs[-1]))
                     extra_in.append(outs[-2])
         ctx.net, ctx.xs, ctx.lat, ctx.extra_in = net, xs, lat, extra_in
+        if DEBUG_CAPTURE is not None:
+            DEBUG_CAPTURE['fpn'] = (xs, lat)
         ctx.out_hw = [_hw(o) for o in outs]
         ctx.out_meta = (outs[0].shape[0], outs[0].shape[3], outs[0].device)
         return tuple(_as_nchw(o) for o in outs)
