@@ -84,13 +84,34 @@ class KernelTimer(object):
         return sum(ms) / len(ms), n, len(ms)
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask and cgroup CPU quota, not the machine total
+    (a 1-GPU box exposes 256 logical CPUs but grants a 16-core share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    cap = int(os.environ.get("TDN_BENCH_CPU_THREADS", "16"))
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(depth, iters=2):
     """The CPU oracle (restatement of the reference's PyTorch-CPU path, bit-equal to it: oracle/gen_golden.py)
     timed on this host's cores on a bounded sample: `iters` fwd+bwd passes of ONE 3x800x1344 image."""
     from golden_util import det_tensor
     from oracle import torch_ref as O
     import torch_detection_amd as T
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     rb, rf = T.ResNet(depth), T.FPN([256, 512, 1024, 2048], 256, 5)
@@ -152,7 +173,10 @@ def main():
     with torch.no_grad():
         outs = neck(backbone(x))
     g2 = torch.Generator(device="cpu").manual_seed(2)
-    cots = [(torch.randn(o.shape, generator=g2) / o[0].numel()).to(device=device, dtype=o.dtype) for o in outs]
+    # cotangents in the layout the outputs have (NCHW-shaped, channels_last strides), as a head consuming the
+    # pyramid on this path would hand them back
+    cots = [(torch.randn(o.shape, generator=g2) / o[0].numel()).to(device=device, dtype=o.dtype)
+            .contiguous(memory_format=torch.channels_last) for o in outs]
     del outs
 
     reducer = dp.attach_reducer([neck, backbone], bucket_bytes=args.bucket_mb << 20) if world > 1 else None

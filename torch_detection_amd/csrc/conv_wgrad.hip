@@ -204,7 +204,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   }
 }
 
-// One block per output channel: reduce split-K slabs in order, scale, and produce affine grads.
+// One block per output channel: reduce the split-K slabs in a fixed order, scale, and produce affine grads.
+// The 256 threads are arranged as K4P k-lanes (float4 each) x SL split-lanes so that short rows (Ktot = 64)
+// still use the whole block; split-lane partial sums are combined through LDS in lane order (deterministic).
 //   map_mode 0: dw index = co*Ktot + k  ([Cout][kh][kw][Cin] = channels_last view of the OIHW grad)
 //   map_mode 1: stem, k = (kh*8 + kw)*4 + c  ->  dw[co][c][kh][kw] contiguous (pads dropped)
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ slab,
@@ -214,39 +216,80 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, float* dw,
                                                              float* dgamma, float* dbeta, float beta,
-                                                             int map_mode) {
-  const int co = blockIdx.x;
-  const float sc = scale ? scale[co] : 1.f;
-  float dot = 0.f;
-  for (int k = threadIdx.x; k < Ktot; k += 256) {
-    float s = 0.f;
-    for (int sp = 0; sp < splitk; ++sp) s += slab[((int64_t)sp * Cout + co) * Ktot + k];
-    dot += (float)w_fwd[(int64_t)co * Ktot + k] * s;
-    int64_t oidx;
-    if (map_mode == 0) {
-      oidx = (int64_t)co * Ktot + k;
-    } else {
-      const int c = k & 3, kw = (k >> 2) & 7, kh = k >> 5;
-      if (c == 3 || kw == 7) continue;
-      oidx = (int64_t)co * 147 + c * 49 + kh * 7 + kw;
-    }
-    const float v = sc * s;
-    dw[oidx] = (beta != 0.f) ? beta * dw[oidx] + v : v;
-  }
-  // block reduce dot
+                                                             int map_mode, int K4P) {
+  __shared__ f32x4_t part[256];
   __shared__ float red[4];
+  const int co = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float sc = scale ? scale[co] : 1.f;
+  const int K4 = Ktot >> 2;
+  const int SL = 256 / K4P;
+  const int k4l = tid % K4P, spl = tid / K4P;
+  const f32x4_t* slab4 = (const f32x4_t*)slab;
+  float dot = 0.f;
+  for (int base = 0; base < K4; base += K4P) {
+    const int k4 = base + k4l;
+    const bool active = k4 < K4;
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      int sp = spl;
+      for (; sp + 3 * SL < splitk; sp += 4 * SL) {   // 4 independent loads in flight
+        const f32x4_t a0 = slab4[((int64_t)sp * Cout + co) * K4 + k4];
+        const f32x4_t a1 = slab4[((int64_t)(sp + SL) * Cout + co) * K4 + k4];
+        const f32x4_t a2 = slab4[((int64_t)(sp + 2 * SL) * Cout + co) * K4 + k4];
+        const f32x4_t a3 = slab4[((int64_t)(sp + 3 * SL) * Cout + co) * K4 + k4];
+        s += (a0 + a1) + (a2 + a3);
+      }
+      for (; sp < splitk; sp += SL) s += slab4[((int64_t)sp * Cout + co) * K4 + k4];
+    }
+    if (SL > 1) {
+      part[tid] = s;
+      __syncthreads();
+      if (spl == 0) {
+        for (int j = 1; j < SL; ++j) s += part[j * K4P + k4l];
+      }
+      __syncthreads();
+    }
+    if (active && spl == 0) {
+      const int k = k4 * 4;
+      const bf16x4_t wv = *(const bf16x4_t*)(w_fwd + (int64_t)co * Ktot + k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dot += (float)wv[e] * s[e];
+      if (map_mode == 0) {
+        f32x4_t* o = (f32x4_t*)(dw + (int64_t)co * Ktot + k);
+        f32x4_t v = s * sc;
+        if (beta != 0.f) v += *o * beta;
+        *o = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = k + e;
+          const int c = kk & 3, kw = (kk >> 2) & 7, kh = kk >> 5;
+          if (c == 3 || kw == 7) continue;
+          const int64_t oidx = (int64_t)co * 147 + c * 49 + kh * 7 + kw;
+          const float v = sc * s[e];
+          dw[oidx] = (beta != 0.f) ? beta * dw[oidx] + v : v;
+        }
+      }
+    }
+  }
+  // block reduce dot; colsum over splits by wave 1
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  if ((tid & 63) == 0) red[tid >> 6] = dot;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float d = (red[0] + red[1]) + (red[2] + red[3]);
+  if (tid < 64) {
     float cs = 0.f;
-    for (int sp = 0; sp < splitk; ++sp) cs += colsum[(int64_t)sp * Cout + co];
-    if (dbeta) dbeta[co] = (beta != 0.f) ? beta * dbeta[co] + cs : cs;
-    if (mean && invstd && dgamma) {
-      const float dg = (d - mean[co] * cs) * invstd[co];
-      dgamma[co] = (beta != 0.f) ? beta * dgamma[co] + dg : dg;
+    for (int sp = tid; sp < splitk; sp += 64) cs += colsum[(int64_t)sp * Cout + co];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cs += __shfl_down(cs, o, 64);
+    if (tid == 0) {
+      const float d = (red[0] + red[1]) + (red[2] + red[3]);
+      if (dbeta) dbeta[co] = (beta != 0.f) ? beta * dbeta[co] + cs : cs;
+      if (mean && invstd && dgamma) {
+        const float dg = (d - mean[co] * cs) * invstd[co];
+        dgamma[co] = (beta != 0.f) ? beta * dgamma[co] + dg : dg;
+      }
     }
   }
 }
@@ -263,9 +306,14 @@ static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps) {
   w.M = M;
   w.Ktot = ntaps * Ktap;
   const int tiles = w.tiles_co * w.tiles_k;
-  // aim for ~1024 workgroups, at least 512 pixels of reduction each
-  int splitk = ceil_div(1024, tiles);
-  const int max_split = ceil_div(M, 512) > 0 ? ceil_div(M, 512) : 1;
+  // Aim for ~512 workgroups (two 64 KB-LDS workgroups fit a CU) but keep each split >= 1024 pixels deep: every
+  // workgroup writes a full fp32 tile slab, so short splits turn the kernel (and the finalize pass that re-reads
+  // the slabs) into an HBM-bound slab copy.
+  int target = 512, min_chunk = 1024;
+  if (const char* env = getenv("TDN_WGRAD_WGS")) target = atoi(env) > 0 ? atoi(env) : target;
+  if (const char* env = getenv("TDN_WGRAD_MINCHUNK")) min_chunk = atoi(env) > 0 ? atoi(env) : min_chunk;
+  int splitk = ceil_div(target, tiles);
+  const int max_split = ceil_div(M, min_chunk) > 0 ? ceil_div(M, min_chunk) : 1;
   if (splitk > max_split) splitk = max_split;
   if (splitk > 256) splitk = 256;
   if (splitk < 1) splitk = 1;
@@ -307,8 +355,11 @@ static int run_wgrad(WgradParams& p, const WgradPlan& w, const void* w_fwd, cons
   else if (w.bmw == 64 && w.bnw == 32) rc = launch_wgrad<64, 32>(p, stream);
   else { tdn_set_error("wgrad: no kernel for tile %dx%d", w.bmw, w.bnw); return -1; }
   if (rc) return rc;
+  int k4p = 1;
+  while (k4p < (w.Ktot >> 2) && k4p < 256) k4p <<= 1;
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(p.Cout), dim3(256), 0, stream, p.slab, p.colsum, w.splitk,
-                     p.Cout, w.Ktot, (const bf16_t*)w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, map_mode);
+                     p.Cout, w.Ktot, (const bf16_t*)w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, map_mode,
+                     k4p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
