@@ -45,18 +45,32 @@ __device__ __forceinline__ int swz_f(int row) {
   else return (4 - ((row >> 2) & 3)) & 3;
 }
 
-template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
+// Counted wait on the vector-memory queue + workgroup barrier in ONE asm statement: the compiler may not move
+// LDS reads / LDS-DMA issues across it, and it does not drain the DMA queue (a __syncthreads() would).
+template <int N>
+__device__ __forceinline__ void wait_vm_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// <BM x BN> output tile (pixels x channels), BK-deep K-steps, WM x WN waves (wave tile BM/WM x BN/WN),
+// NSTAGE-deep LDS ring filled by LDS-DMA: while K-step t is multiplied, the loads of steps t+1 .. t+NSTAGE-2 stay
+// in flight (counted vmcnt, one s_barrier per K-step).
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = WM * WN;
   constexpr int ROWB = BK * 2;
   constexpr int CH = BK / 8;
   constexpr int RPI = 64 / CH;
-  constexpr int A_IT = BM / (RPI * 4);
-  constexpr int B_IT = BN / (RPI * 4);
+  constexpr int A_IT = BM / (RPI * NW);
+  constexpr int B_IT = BN / (RPI * NW);
+  constexpr int LOADS = A_IT + B_IT;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-  constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
   constexpr int KSUB = BK / 32;
-  static_assert(A_IT >= 1 && B_IT >= 1 && FM >= 1 && FN >= 1, "tile too small");
+  static_assert(A_IT >= 1 && B_IT >= 1 && FM >= 1 && FN >= 1, "tile too small for this wave layout");
+  static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "loader does not tile evenly");
+  static_assert(NSTAGE >= 2 && LOADS * (NSTAGE - 2) < 64, "vmcnt immediate out of range");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -72,13 +86,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
 
   // ---- loader thread constants ----
   const int lrow = lane / CH, lchunk = lane % CH;
-  const int ld_row = wave * RPI + lrow;                     // + it*RPI*4
+  const int ld_row = wave * RPI + lrow;                       // + it*RPI*NW
   const int src_chunk_el = (lchunk ^ swz_f<BK>(ld_row)) * 8;  // element offset of the 16B chunk this lane fetches
   const int HaWa = c.Ha * c.Wa;
   int a_pix[A_IT], a_h[A_IT], a_w[A_IT];
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
-    const int m = m0 + it * (RPI * 4) + ld_row;
+    const int m = m0 + it * (RPI * NW) + ld_row;
     if (m < c.M) {
       const int img = m / HaWa;
       const int rem = m - img * HaWa;
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
   const bf16_t* b_src[B_IT];
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
-    const int n = n0 + it * (RPI * 4) + ld_row;
+    const int n = n0 + it * (RPI * NW) + ld_row;
     b_src[it] = p.wt + (int64_t)n * p.wt_row + src_chunk_el;
   }
   const bf16_t* zero_src = (const bf16_t*)g_zero_page + src_chunk_el;
@@ -104,29 +118,37 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
   const int kchunks = p.Ktap / BK;
   const int T = c.ntaps * kchunks;
 
+  // issue the LDS-DMA of K-step t into ring slot s (t >= T: dummy loads of the zero page keep the count uniform)
   auto stage_load = [&](int t, int s) {
-    const int tap_i = t / kchunks;
-    const int kc = t - tap_i * kchunks;
-    const int tp = c.taps[tap_i];
-    const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
     char* sA = smem + s * STAGE + wave * (RPI * ROWB);
     char* sB = sA + A_BYTES;
-    const int koff_a = kc * BK;
-    const int dpix = dh * p.Win + dw;
+    if (t < T) {
+      const int tap_i = t / kchunks;
+      const int kc = t - tap_i * kchunks;
+      const int tp = c.taps[tap_i];
+      const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
+      const int koff_a = kc * BK;
+      const int dpix = dh * p.Win + dw;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int h = a_h[it] + dh, w = a_w[it] + dw;
-      const bool ok = ((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win);
-      const bf16_t* src = ok ? p.in + ((int64_t)(a_pix[it] + dpix) * p.Cpix + koff_a + src_chunk_el) : zero_src;
-      glds16(src, sA + it * (RPI * 4 * ROWB));
+      for (int it = 0; it < A_IT; ++it) {
+        const int h = a_h[it] + dh, w = a_w[it] + dw;
+        const bool ok = ((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win);
+        const bf16_t* src = ok ? p.in + ((int64_t)(a_pix[it] + dpix) * p.Cpix + koff_a + src_chunk_el) : zero_src;
+        glds16(src, sA + it * (RPI * NW * ROWB));
+      }
+      const int koff_b = widx * p.Ktap + kc * BK;
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it) glds16(b_src[it] + koff_b, sB + it * (RPI * NW * ROWB));
+    } else {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) glds16(zero_src, sA + it * (RPI * NW * ROWB));
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it) glds16(zero_src, sB + it * (RPI * NW * ROWB));
     }
-    const int koff_b = widx * p.Ktap + kc * BK;
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) glds16(b_src[it] + koff_b, sB + it * (RPI * 4 * ROWB));
   };
 
   // ---- fragment reader constants ----
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
   const int f_rd = swz_f<BK>(fr);
   int rd_off[KSUB];
@@ -140,13 +162,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
     for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   if (T > 0) {
-    stage_load(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) stage_load(s, s);
+    int slot = 0, fill = NSTAGE - 1;
     for (int t = 0; t < T; ++t) {
-      if (t + 1 < T) stage_load(t + 1, (t + 1) & 1);
-      const char* sA = smem + (t & 1) * STAGE + (wm * WTM) * ROWB;
-      const char* sB = smem + (t & 1) * STAGE + A_BYTES + (wn * WTN) * ROWB;
+      wait_vm_and_barrier<LOADS * (NSTAGE - 2)>();   // K-step t has landed for every wave; slot (t-1) is free
+      stage_load(t + NSTAGE - 1, fill);
+      const char* sA = smem + slot * STAGE + (wm * WTM) * ROWB;
+      const char* sB = smem + slot * STAGE + A_BYTES + (wn * WTN) * ROWB;
 #pragma unroll
       for (int kk = 0; kk < KSUB; ++kk) {
         bf16x8_t wf[FN], xf[FM];
@@ -160,9 +183,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
           for (int j = 0; j < FM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
+      fill = (fill + 1 == NSTAGE) ? 0 : fill + 1;
     }
+    // drain the dummy tail loads before the LDS ring / registers are reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
   // ---- epilogue: lane owns channels ch..ch+3 of pixel m for each (i, j) fragment ----
@@ -234,51 +259,76 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
 // ---------------------------------------------------------------------------------------------
 static inline int pack_tap(int dh, int dw, int widx) { return (dh + 64) | ((dw + 64) << 8) | (widx << 16); }
 
-struct TileChoice { int bm, bn; };
+// Tile configurations. LDS = NSTAGE * (BM + BN) * BK * 2 bytes.
+struct GemmCfg { int bm, bn, bk, wm, wn, nstage; };
+static const GemmCfg kCfgs[] = {
+    {128, 128, 64, 2, 2, 2},  // 0   64 KB, 256 thr
+    {128, 128, 64, 2, 2, 3},  // 1   96 KB
+    {128, 128, 64, 2, 2, 4},  // 2  128 KB
+    {256, 128, 64, 4, 2, 3},  // 3  144 KB, 512 thr
+    {256, 128, 64, 4, 2, 2},  // 4   96 KB, 512 thr
+    {128, 64, 64, 2, 2, 3},   // 5   72 KB
+    {128, 64, 64, 2, 2, 4},   // 6   96 KB
+    {64, 128, 64, 2, 2, 4},   // 7   96 KB
+    {64, 128, 64, 2, 2, 3},   // 8   72 KB
+    {64, 64, 64, 2, 2, 4},    // 9   64 KB
+    {256, 64, 64, 4, 2, 3},   // 10 120 KB, 512 thr
+    {128, 128, 64, 2, 4, 3},  // 11  96 KB, 512 thr
+};
+static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
-static TileChoice choose_tile(int maxM, int ngemm) {
-  TileChoice t;
-  t.bn = (ngemm % 128 == 0) ? 128 : 64;
-  t.bm = 128;
-  const long tiles = (long)ceil_div(maxM, 128) * (ngemm / t.bn);
-  if (tiles < 384) t.bm = 64;
-  const char* env = getenv("TDN_TILE");
-  if (env) {
-    int bm = 0, bn = 0;
-    if (sscanf(env, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) &&
-        ngemm % bn == 0) {
-      t.bm = bm;
-      t.bn = bn;
-    }
+static int choose_cfg(int maxM, int ngemm) {
+  if (const char* env = getenv("TDN_GEMM_CFG")) {
+    const int id = atoi(env);
+    if (id >= 0 && id < kNumCfgs && ngemm % kCfgs[id].bn == 0) return id;
   }
-  return t;
+  // Measured on MI355X over the R50-FPN shapes (scripts/conv_bench.py, profiles/): two co-resident 64 KB
+  // workgroups beat one deeper ring for large M; 64-pixel tiles win once 128-pixel tiles no longer fill the chip.
+  if (ngemm % 128 == 0) {
+    const long t128 = (long)ceil_div(maxM, 128) * (ngemm / 128);
+    if (maxM >= 100000) return 3;
+    if (t128 >= 256) return 0;
+    return 8;
+  }
+  const long t128 = (long)ceil_div(maxM, 128) * (ngemm / 64);
+  return t128 >= 256 ? 5 : 9;
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
 static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   p.tiles_n = p.Cout / BN;
   const int ntiles = ceil_div(maxM, BM) * p.tiles_n;
   p.nwg_pad = (ntiles + 7) & ~7;
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+  constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, BK>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
     attr_set = true;
   }
-  dim3 grid(p.nwg_pad, p.ncls, 1), block(256, 1, 1);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK>), grid, block, lds, stream, p);
+  dim3 grid(p.nwg_pad, p.ncls, 1), block(WM * WN * 64, 1, 1);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE>), grid, block, lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
 static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   if (maxM <= 0) return 0;
-  const TileChoice t = choose_tile(maxM, p.Cout);
-  if (t.bm == 128 && t.bn == 128) return launch_gemm<128, 128, 64>(p, maxM, stream);
-  if (t.bm == 128 && t.bn == 64) return launch_gemm<128, 64, 64>(p, maxM, stream);
-  if (t.bm == 64 && t.bn == 128) return launch_gemm<64, 128, 64>(p, maxM, stream);
-  return launch_gemm<64, 64, 64>(p, maxM, stream);
+  switch (choose_cfg(maxM, p.Cout)) {
+    case 0: return launch_gemm<128, 128, 64, 2, 2, 2>(p, maxM, stream);
+    case 1: return launch_gemm<128, 128, 64, 2, 2, 3>(p, maxM, stream);
+    case 2: return launch_gemm<128, 128, 64, 2, 2, 4>(p, maxM, stream);
+    case 3: return launch_gemm<256, 128, 64, 4, 2, 3>(p, maxM, stream);
+    case 4: return launch_gemm<256, 128, 64, 4, 2, 2>(p, maxM, stream);
+    case 5: return launch_gemm<128, 64, 64, 2, 2, 3>(p, maxM, stream);
+    case 6: return launch_gemm<128, 64, 64, 2, 2, 4>(p, maxM, stream);
+    case 7: return launch_gemm<64, 128, 64, 2, 2, 4>(p, maxM, stream);
+    case 8: return launch_gemm<64, 128, 64, 2, 2, 3>(p, maxM, stream);
+    case 9: return launch_gemm<64, 64, 64, 2, 2, 4>(p, maxM, stream);
+    case 10: return launch_gemm<256, 64, 64, 4, 2, 3>(p, maxM, stream);
+    default: return launch_gemm<128, 128, 64, 2, 4, 3>(p, maxM, stream);
+  }
 }
 
 static int fill_epilogue(GemmParams& p, const tdn_epilogue* ep, int Hout, int Wout) {
@@ -397,7 +447,7 @@ extern "C" int tdn_stem_conv_fwd(const void* xp, const void* w_stem, void* y, in
   for (int kh = 0; kh < 7; ++kh) c.taps[kh] = pack_tap(kh, 0, kh);
   p.in = (const bf16_t*)xp; p.wt = (const bf16_t*)w_stem; p.out = (bf16_t*)y;
   if (fill_epilogue(p, ep, Ho, Wo)) return -1;
-  return launch_gemm<128, 64, 32>(p, c.M, (hipStream_t)stream);
+  return launch_gemm<128, 64, 32, 2, 2, 3>(p, c.M, (hipStream_t)stream);
 }
 
 extern "C" int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad,
@@ -415,10 +465,10 @@ extern "C" int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout,
   int maxM;
   if (kind == 0) { build_fwd(p, N, H, W, Cin, Cout, k, stride, pad); maxM = p.cls[0].M; }
   else maxM = build_dgrad(p, N, H, W, Cin, Cout, k, stride, pad);
-  const TileChoice t = choose_tile(maxM, p.Cout);
+  const GemmCfg& t = kCfgs[choose_cfg(maxM, p.Cout)];
   int Mtot = 0, taps_tot = 0;
   for (int i = 0; i < p.ncls; ++i) { Mtot += p.cls[i].M; taps_tot += p.cls[i].ntaps; }
-  o[0] = Mtot; o[1] = p.Cout; o[2] = p.cls[0].ntaps * p.Ktap; o[3] = t.bm; o[4] = t.bn; o[5] = 64;
+  o[0] = Mtot; o[1] = p.Cout; o[2] = p.cls[0].ntaps * p.Ktap; o[3] = t.bm; o[4] = t.bn; o[5] = t.bk;
   o[6] = (ceil_div(maxM, t.bm) * (p.Cout / t.bn) + 7) & ~7; o[7] = p.ncls; o[8] = 1; o[9] = p.ncls;
   o[10] = p.cls[0].ntaps; o[11] = 1; o[12] = taps_tot; o[13] = p.Hout; o[14] = p.Wout; o[15] = maxM;
   return 0;
