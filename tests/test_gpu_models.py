@@ -139,7 +139,7 @@ def test_resnet_fpn_fwd_bwd_in_situ(T, depth, shape):
     import parity_util
     res = parity_util.run_teacher_forced(T, depth, shape)
     _record("r%d_fpn_%dx%d" % (depth, shape[2], shape[3]), res)
-    parity_util.check(res)
+    parity_util.check(res, depth)
 
 
 def test_resnet_api_semantics(T, manifest):

@@ -55,7 +55,9 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // <BM x BN> output tile (pixels x channels), BK-deep K-steps, WM x WN waves (wave tile BM/WM x BN/WN),
 // NSTAGE-deep LDS ring filled by LDS-DMA: while K-step t is multiplied, the loads of steps t+1 .. t+NSTAGE-2 stay
 // in flight (counted vmcnt, one s_barrier per K-step).
-template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
+// MODE 0: LDS-DMA issued right after the barrier;  MODE 1: LDS-DMA issued between the two MFMA sub-steps.
+// (Register staging — global_load_dwordx4 -> VGPR -> ds_write_b128 — measured the same as LDS-DMA and was dropped.)
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WM * WN;
@@ -89,56 +91,68 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
   const int ld_row = wave * RPI + lrow;                       // + it*RPI*NW
   const int src_chunk_el = (lchunk ^ swz_f<BK>(ld_row)) * 8;  // element offset of the 16B chunk this lane fetches
   const int HaWa = c.Ha * c.Wa;
-  int a_pix[A_IT], a_h[A_IT], a_w[A_IT];
+  // Per lane and tile row, everything that does not change over the K loop is computed once: the byte address of
+  // the row's first channel chunk (tap (0,0)) and a bitmask of the taps that fall inside the image.  Per K-step
+  // only a wave-uniform byte offset is added (tap displacement + channel chunk) — the gather costs ~6 VALU per row.
+  const char* a_base[A_IT];
+  unsigned a_valid[A_IT];
+  const char* zero_src = (const char*)g_zero_page + src_chunk_el * 2;
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int m = m0 + it * (RPI * NW) + ld_row;
+    a_valid[it] = 0u;
+    a_base[it] = zero_src;
     if (m < c.M) {
       const int img = m / HaWa;
       const int rem = m - img * HaWa;
       const int a = rem / c.Wa;
       const int b = rem - a * c.Wa;
-      a_h[it] = a * p.sa;
-      a_w[it] = b * p.sa;
-      a_pix[it] = (img * p.Hin + a_h[it]) * p.Win + a_w[it];
-    } else {
-      a_h[it] = -(1 << 24);
-      a_w[it] = 0;
-      a_pix[it] = 0;
+      const int h0 = a * p.sa, w0 = b * p.sa;
+      a_base[it] = (const char*)p.in + ((int64_t)((img * p.Hin + h0) * p.Win + w0) * p.Cpix + src_chunk_el) * 2;
+      for (int ti = 0; ti < c.ntaps; ++ti) {
+        const int tp = c.taps[ti];
+        const int h = h0 + (tp & 0xff) - 64, w = w0 + ((tp >> 8) & 0xff) - 64;
+        if (((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win)) a_valid[it] |= 1u << ti;
+      }
     }
   }
-  const bf16_t* b_src[B_IT];
+  unsigned b_off[B_IT];   // byte offset of this lane's chunk of weight row n (tap 0, k 0); fits 32 bits
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
     const int n = n0 + it * (RPI * NW) + ld_row;
-    b_src[it] = p.wt + (int64_t)n * p.wt_row + src_chunk_el;
+    b_off[it] = (unsigned)(((int64_t)n * p.wt_row + src_chunk_el) * 2);
   }
-  const bf16_t* zero_src = (const bf16_t*)g_zero_page + src_chunk_el;
 
   const int kchunks = p.Ktap / BK;
   const int T = c.ntaps * kchunks;
+  // K order: channel chunk outermost, taps innermost.  All taps of a chunk touch the same input lines (shifted by
+  // a pixel or a row), so within ~ntaps K-steps the workgroups of an XCD re-read a working set of
+  // (pixels + halo) x 128 B instead of cycling through the whole (pixels x Cin) slab — the latter overflows the
+  // 4 MB L2 for 256-channel 3x3 layers and drops the LDS-DMA stream to Infinity-Cache speed (~10 TB/s measured).
+  int ld_tap = 0, ld_kc = 0;   // (tap, channel chunk) of the next K-step to be issued: stage_load runs in t order
+  // tap table in a VGPR (lane i = tap i) and fetched with v_readlane: a scalar load per K-step would put an
+  // s_waitcnt lgkmcnt(0) — which also drains the LDS fragment reads — on the critical path
+  const int tapv = (lane < c.ntaps) ? c.taps[lane < 9 ? lane : 0] : 0;
 
-  // issue the LDS-DMA of K-step t into ring slot s (t >= T: dummy loads of the zero page keep the count uniform)
-  auto stage_load = [&](int t, int s) {
+  // issue the LDS-DMA of the next K-step into ring slot s (past the end: dummy loads of the zero page keep the
+  // vmcnt bookkeeping uniform)
+  auto stage_load = [&](int s) {
     char* sA = smem + s * STAGE + wave * (RPI * ROWB);
     char* sB = sA + A_BYTES;
-    if (t < T) {
-      const int tap_i = t / kchunks;
-      const int kc = t - tap_i * kchunks;
-      const int tp = c.taps[tap_i];
+    if (ld_kc < kchunks) {
+      const int tp = __builtin_amdgcn_readlane(tapv, ld_tap);
       const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
-      const int koff_a = kc * BK;
-      const int dpix = dh * p.Win + dw;
+      const int64_t uoff_a = ((int64_t)(dh * p.Win + dw) * p.Cpix + ld_kc * BK) * 2;   // wave-uniform
+      const char* wt_u = (const char*)p.wt + ((int64_t)widx * p.Ktap + ld_kc * BK) * 2;  // wave-uniform
+      const unsigned bit = 1u << ld_tap;
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
-        const int h = a_h[it] + dh, w = a_w[it] + dw;
-        const bool ok = ((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win);
-        const bf16_t* src = ok ? p.in + ((int64_t)(a_pix[it] + dpix) * p.Cpix + koff_a + src_chunk_el) : zero_src;
+        const char* src = (a_valid[it] & bit) ? a_base[it] + uoff_a : zero_src;
         glds16(src, sA + it * (RPI * NW * ROWB));
       }
-      const int koff_b = widx * p.Ktap + kc * BK;
 #pragma unroll
-      for (int it = 0; it < B_IT; ++it) glds16(b_src[it] + koff_b, sB + it * (RPI * NW * ROWB));
+      for (int it = 0; it < B_IT; ++it) glds16(wt_u + b_off[it], sB + it * (RPI * NW * ROWB));
+      if (++ld_tap == c.ntaps) { ld_tap = 0; ++ld_kc; }   // taps innermost (see K-order note above)
     } else {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) glds16(zero_src, sA + it * (RPI * NW * ROWB));
@@ -161,27 +175,60 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  auto mfma_substep = [&](const char* sA, const char* sB, int kk) {
+    bf16x8_t wf[FN], xf[FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) wf[i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[kk]);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) xf[j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[kk]);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  };
+
   if (T > 0) {
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s) stage_load(s, s);
+    for (int s = 0; s < NSTAGE - 1; ++s) stage_load(s);
     int slot = 0, fill = NSTAGE - 1;
     for (int t = 0; t < T; ++t) {
       wait_vm_and_barrier<LOADS * (NSTAGE - 2)>();   // K-step t has landed for every wave; slot (t-1) is free
-      stage_load(t + NSTAGE - 1, fill);
       const char* sA = smem + slot * STAGE + (wm * WTM) * ROWB;
       const char* sB = smem + slot * STAGE + A_BYTES + (wn * WTN) * ROWB;
+      if constexpr (MODE == 0) {
+        stage_load(fill);
 #pragma unroll
-      for (int kk = 0; kk < KSUB; ++kk) {
-        bf16x8_t wf[FN], xf[FM];
+        for (int kk = 0; kk < KSUB; ++kk) mfma_substep(sA, sB, kk);
+      } else if constexpr (MODE == 3) {   // ABLATION (timing only, wrong results): no loads in the K loop
 #pragma unroll
-        for (int i = 0; i < FN; ++i) wf[i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[kk]);
+        for (int kk = 0; kk < KSUB; ++kk) mfma_substep(sA, sB, kk);
+      } else if constexpr (MODE == 4) {   // ABLATION (timing only, wrong results): loads only, no LDS reads / MFMA
+        stage_load(fill);
+      } else if constexpr (MODE == 2) {
+        // all fragment reads of the K-step first (one exposed LDS latency per step instead of one per
+        // read group), the LDS-DMA of the next step behind them, then the MFMAs
+        bf16x8_t wf[KSUB][FN], xf[KSUB][FM];
 #pragma unroll
-        for (int j = 0; j < FM; ++j) xf[j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[kk]);
+        for (int kk = 0; kk < KSUB; ++kk) {
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
+          for (int i = 0; i < FN; ++i) wf[kk][i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[kk]);
 #pragma unroll
-          for (int j = 0; j < FM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < FM; ++j) xf[kk][j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[kk]);
+        }
+        stage_load(fill);
+#pragma unroll
+        for (int kk = 0; kk < KSUB; ++kk)
+#pragma unroll
+          for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+      } else {
+        mfma_substep(sA, sB, 0);
+        stage_load(fill);
+#pragma unroll
+        for (int kk = 1; kk < KSUB; ++kk) mfma_substep(sA, sB, kk);
       }
       slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
       fill = (fill + 1 == NSTAGE) ? 0 : fill + 1;
@@ -260,20 +307,63 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
 static inline int pack_tap(int dh, int dw, int widx) { return (dh + 64) | ((dw + 64) << 8) | (widx << 16); }
 
 // Tile configurations. LDS = NSTAGE * (BM + BN) * BK * 2 bytes.
-struct GemmCfg { int bm, bn, bk, wm, wn, nstage; };
+struct GemmCfg { int bm, bn, bk, wm, wn, nstage, mode; };
 static const GemmCfg kCfgs[] = {
-    {128, 128, 64, 2, 2, 2},  // 0   64 KB, 256 thr
-    {128, 128, 64, 2, 2, 3},  // 1   96 KB
-    {128, 128, 64, 2, 2, 4},  // 2  128 KB
-    {256, 128, 64, 4, 2, 3},  // 3  144 KB, 512 thr
-    {256, 128, 64, 4, 2, 2},  // 4   96 KB, 512 thr
-    {128, 64, 64, 2, 2, 3},   // 5   72 KB
-    {128, 64, 64, 2, 2, 4},   // 6   96 KB
-    {64, 128, 64, 2, 2, 4},   // 7   96 KB
-    {64, 128, 64, 2, 2, 3},   // 8   72 KB
-    {64, 64, 64, 2, 2, 4},    // 9   64 KB
-    {256, 64, 64, 4, 2, 3},   // 10 120 KB, 512 thr
-    {128, 128, 64, 2, 4, 3},  // 11  96 KB, 512 thr
+    {128, 128, 64, 2, 2, 2, 0},  // 0   64 KB, 256 thr
+    {128, 128, 64, 2, 2, 3, 0},  // 1   96 KB
+    {128, 128, 64, 2, 2, 4, 0},  // 2  128 KB
+    {256, 128, 64, 4, 2, 3, 0},  // 3  144 KB, 512 thr
+    {256, 128, 64, 4, 2, 2, 0},  // 4   96 KB, 512 thr
+    {128, 64, 64, 2, 2, 3, 0},   // 5   72 KB
+    {128, 64, 64, 2, 2, 4, 0},   // 6   96 KB
+    {64, 128, 64, 2, 2, 4, 0},   // 7   96 KB
+    {64, 128, 64, 2, 2, 3, 0},   // 8   72 KB
+    {64, 64, 64, 2, 2, 4, 0},    // 9   64 KB
+    {256, 64, 64, 4, 2, 3, 0},   // 10 120 KB, 512 thr
+    {128, 128, 64, 2, 4, 3, 0},  // 11  96 KB, 512 thr
+    {128, 128, 64, 2, 2, 2, 1},  // 12  mid-issue DMA
+    {128, 128, 64, 2, 2, 3, 1},  // 13
+    {256, 128, 64, 4, 2, 3, 1},  // 14
+    {256, 128, 64, 4, 2, 2, 1},  // 15
+    {64, 128, 64, 2, 2, 3, 1},   // 16
+    {64, 128, 64, 2, 2, 2, 0},   // 17
+    {128, 64, 64, 2, 2, 2, 0},   // 18
+    {64, 64, 64, 2, 2, 2, 0},    // 19
+    {64, 128, 32, 2, 2, 2, 0},   // 20  24 KB
+    {64, 128, 32, 2, 2, 3, 0},   // 21  36 KB
+    {64, 128, 32, 2, 2, 4, 0},   // 22  48 KB
+    {128, 128, 32, 2, 2, 2, 0},  // 23  32 KB
+    {128, 128, 32, 2, 2, 3, 0},  // 24  48 KB
+    {32, 128, 64, 1, 4, 2, 0},   // 25  40 KB
+    {64, 256, 64, 2, 2, 2, 0},   // 26  80 KB
+    {128, 256, 64, 2, 2, 2, 0},  // 27  96 KB
+    {64, 128, 64, 2, 2, 2, 2},   // 28  reads-first
+    {128, 128, 64, 2, 2, 2, 2},  // 29
+    {256, 128, 64, 4, 2, 3, 2},  // 30
+    {64, 64, 64, 2, 2, 2, 2},    // 31
+    {256, 256, 32, 2, 4, 4, 0},  // 32  128 KB, 512 thr, wave tile 128x64
+    {256, 256, 64, 2, 4, 2, 0},  // 33  128 KB
+    {192, 256, 64, 2, 4, 2, 0},  // 34  112 KB
+    {256, 256, 32, 2, 4, 4, 2},  // 35  reads-first
+    {256, 128, 32, 4, 2, 4, 0},  // 36   96 KB
+    {128, 256, 64, 2, 4, 2, 0},  // 37   96 KB, 512 thr
+    {192, 256, 64, 2, 4, 2, 3},  // 38  ablation: compute only
+    {192, 256, 64, 2, 4, 2, 4},  // 39  ablation: loads only
+    {192, 256, 64, 2, 4, 2, 2},  // 40  reads-first
+    {192, 256, 64, 2, 4, 2, 1},  // 41  mid-issue
+    {192, 128, 64, 2, 4, 2, 0},  // 42  80 KB, wave tile 96x32
+    {192, 128, 64, 2, 2, 2, 0},  // 43  80 KB, 256 thr, wave tile 96x64
+    {256, 256, 32, 2, 4, 4, 4},  // 44  loads only
+    {128, 256, 32, 2, 4, 6, 4},  // 45  loads only, 6 x 24 KB
+    {64, 128, 64, 2, 2, 2, 4},   // 46  loads only
+    {128, 256, 32, 2, 4, 6, 0},  // 47  144 KB, 6-deep ring
+    {128, 256, 32, 2, 4, 4, 0},  // 48   96 KB
+    {256, 128, 32, 4, 2, 5, 0},  // 49  120 KB
+    {256, 256, 64, 4, 4, 2, 0},  // 50  128 KB, 1024 thr, wave tile 64x64
+    {128, 256, 64, 2, 8, 2, 0},  // 51   96 KB, 1024 thr, wave tile 64x32
+    {256, 128, 64, 4, 4, 2, 0},  // 52   96 KB, 1024 thr, wave tile 64x32
+    {256, 256, 64, 4, 4, 2, 4},  // 53  loads only
+    {256, 256, 64, 4, 4, 2, 3},  // 54  compute only
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -282,19 +372,19 @@ static int choose_cfg(int maxM, int ngemm) {
     const int id = atoi(env);
     if (id >= 0 && id < kNumCfgs && ngemm % kCfgs[id].bn == 0) return id;
   }
-  // Measured on MI355X over the R50-FPN shapes (scripts/conv_bench.py, profiles/): two co-resident 64 KB
-  // workgroups beat one deeper ring for large M; 64-pixel tiles win once 128-pixel tiles no longer fill the chip.
+  // Measured on MI355X over the R50-FPN shapes (scripts/conv_bench.py; profiles/convbench_*.log): several small
+  // co-resident workgroups per CU (64-pixel tiles, 2-deep ring, 32-48 KB LDS) beat one large deeply pipelined
+  // workgroup on almost every shape; only the very large-M 3x3 convs prefer the 256x128 8-wave tile.
+  if (ngemm % 256 == 0 && maxM >= 24000) return 34;   // 192x256, 8 waves: fewest L2->LDS bytes per flop
   if (ngemm % 128 == 0) {
-    const long t128 = (long)ceil_div(maxM, 128) * (ngemm / 128);
-    if (maxM >= 100000) return 3;
-    if (t128 >= 256) return 0;
-    return 8;
+    if (maxM >= 100000) return 14;
+    const long t64 = (long)ceil_div(maxM, 64) * (ngemm / 128);
+    return t64 >= 300 ? 17 : 19;
   }
-  const long t128 = (long)ceil_div(maxM, 128) * (ngemm / 64);
-  return t128 >= 256 ? 5 : 9;
+  return 19;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0>
 static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   p.tiles_n = p.Cout / BN;
   const int ntiles = ceil_div(maxM, BM) * p.tiles_n;
@@ -302,13 +392,13 @@ static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
     attr_set = true;
   }
   dim3 grid(p.nwg_pad, p.ncls, 1), block(WM * WN * 64, 1, 1);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE>), grid, block, lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -327,7 +417,50 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
     case 8: return launch_gemm<64, 128, 64, 2, 2, 3>(p, maxM, stream);
     case 9: return launch_gemm<64, 64, 64, 2, 2, 4>(p, maxM, stream);
     case 10: return launch_gemm<256, 64, 64, 4, 2, 3>(p, maxM, stream);
-    default: return launch_gemm<128, 128, 64, 2, 4, 3>(p, maxM, stream);
+    case 11: return launch_gemm<128, 128, 64, 2, 4, 3>(p, maxM, stream);
+    case 12: return launch_gemm<128, 128, 64, 2, 2, 2, 1>(p, maxM, stream);
+    case 13: return launch_gemm<128, 128, 64, 2, 2, 3, 1>(p, maxM, stream);
+    case 14: return launch_gemm<256, 128, 64, 4, 2, 3, 1>(p, maxM, stream);
+    case 15: return launch_gemm<256, 128, 64, 4, 2, 2, 1>(p, maxM, stream);
+    case 16: return launch_gemm<64, 128, 64, 2, 2, 3, 1>(p, maxM, stream);
+    case 17: return launch_gemm<64, 128, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 18: return launch_gemm<128, 64, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 19: return launch_gemm<64, 64, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 20: return launch_gemm<64, 128, 32, 2, 2, 2, 0>(p, maxM, stream);
+    case 21: return launch_gemm<64, 128, 32, 2, 2, 3, 0>(p, maxM, stream);
+    case 22: return launch_gemm<64, 128, 32, 2, 2, 4, 0>(p, maxM, stream);
+    case 23: return launch_gemm<128, 128, 32, 2, 2, 2, 0>(p, maxM, stream);
+    case 24: return launch_gemm<128, 128, 32, 2, 2, 3, 0>(p, maxM, stream);
+    case 25: return launch_gemm<32, 128, 64, 1, 4, 2, 0>(p, maxM, stream);
+    case 26: return launch_gemm<64, 256, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 27: return launch_gemm<128, 256, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 28: return launch_gemm<64, 128, 64, 2, 2, 2, 2>(p, maxM, stream);
+    case 29: return launch_gemm<128, 128, 64, 2, 2, 2, 2>(p, maxM, stream);
+    case 30: return launch_gemm<256, 128, 64, 4, 2, 3, 2>(p, maxM, stream);
+    case 31: return launch_gemm<64, 64, 64, 2, 2, 2, 2>(p, maxM, stream);
+    case 32: return launch_gemm<256, 256, 32, 2, 4, 4, 0>(p, maxM, stream);
+    case 33: return launch_gemm<256, 256, 64, 2, 4, 2, 0>(p, maxM, stream);
+    case 34: return launch_gemm<192, 256, 64, 2, 4, 2, 0>(p, maxM, stream);
+    case 35: return launch_gemm<256, 256, 32, 2, 4, 4, 2>(p, maxM, stream);
+    case 36: return launch_gemm<256, 128, 32, 4, 2, 4, 0>(p, maxM, stream);
+    case 37: return launch_gemm<128, 256, 64, 2, 4, 2, 0>(p, maxM, stream);
+    case 38: return launch_gemm<192, 256, 64, 2, 4, 2, 3>(p, maxM, stream);
+    case 39: return launch_gemm<192, 256, 64, 2, 4, 2, 4>(p, maxM, stream);
+    case 40: return launch_gemm<192, 256, 64, 2, 4, 2, 2>(p, maxM, stream);
+    case 41: return launch_gemm<192, 256, 64, 2, 4, 2, 1>(p, maxM, stream);
+    case 42: return launch_gemm<192, 128, 64, 2, 4, 2, 0>(p, maxM, stream);
+    case 43: return launch_gemm<192, 128, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 44: return launch_gemm<256, 256, 32, 2, 4, 4, 4>(p, maxM, stream);
+    case 45: return launch_gemm<128, 256, 32, 2, 4, 6, 4>(p, maxM, stream);
+    case 46: return launch_gemm<64, 128, 64, 2, 2, 2, 4>(p, maxM, stream);
+    case 47: return launch_gemm<128, 256, 32, 2, 4, 6, 0>(p, maxM, stream);
+    case 48: return launch_gemm<128, 256, 32, 2, 4, 4, 0>(p, maxM, stream);
+    case 49: return launch_gemm<256, 128, 32, 4, 2, 5, 0>(p, maxM, stream);
+    case 50: return launch_gemm<256, 256, 64, 4, 4, 2, 0>(p, maxM, stream);
+    case 51: return launch_gemm<128, 256, 64, 2, 8, 2, 0>(p, maxM, stream);
+    case 52: return launch_gemm<256, 128, 64, 4, 4, 2, 0>(p, maxM, stream);
+    case 53: return launch_gemm<256, 256, 64, 4, 4, 2, 4>(p, maxM, stream);
+    default: return launch_gemm<256, 256, 64, 4, 4, 2, 3>(p, maxM, stream);
   }
 }
 

@@ -28,7 +28,8 @@ class GradReducer(object):
         self.device = torch.device(device)
         self.group = group
         self.average = average
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.enabled = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.enabled else 1
         # 64-element (256 B) alignment of every slot keeps kernels' float4 stores aligned
         self.offsets, off = [], 0
         for n in numels:
@@ -70,7 +71,7 @@ class GradReducer(object):
     def _launch(self, b):
         start, end, _ = self.buckets[b]
         buf = self.flat[start:end]
-        if self.world == 1:
+        if not self.enabled:
             return
         if self.use_streams:
             ev = torch.cuda.Event()
@@ -91,7 +92,7 @@ class GradReducer(object):
                 self._launch(b)
         for w in self._works:
             w.wait()
-        if self.use_streams and self.world > 1:
+        if self.use_streams and self.enabled:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         if self.average and self.world > 1:
             self.flat.mul_(1.0 / self.world)
@@ -131,7 +132,7 @@ def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True):
         if u.is_stem:
             wview = views[0].view(w.shape)
         else:
-            wview = views[0].view(u.Cout, u.k, u.k, u.Cin).permute(0, 3, 1, 2)
+            wview = views[0].view(w.shape) if u.k == 1 else views[0].view(u.Cout, u.k, u.k, u.Cin).permute(0, 3, 1, 2)
         w.grad = wview
         for p, v in zip(ps[1:], views[1:]):
             p.grad = v.view(p.shape)

@@ -160,7 +160,9 @@ def unit_wgrad(u, x_in, g, img_hw=None):
     else:
         dw4 = dw.view(u.Cout, u.k, u.k, u.Cin) if dw is not None else None
         dw4, dg, db = ops.conv2d_wgrad(x_in, g, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.mean, u.invstd, dw4, dg, db)
-        dw_view = dw4.permute(0, 3, 1, 2)
+        # 1x1: [Cout,1,1,Cin] is byte-identical to the contiguous OIHW parameter -> view, so autograd's
+        # layout contract holds and AccumulateGrad does not copy
+        dw_view = dw4.view(u.Cout, u.Cin, 1, 1) if u.k == 1 else dw4.permute(0, 3, 1, 2)
     if u.on_grads is not None:
         u.on_grads(u)
     if sink is not None:
