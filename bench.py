@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -196,22 +197,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- execution mode: one hipGraph per step (single GPU) or eager launches (multi-GPU: RCCL stays eager) ----
+    graph, mode = None, "eager"
+    use_graph = (world == 1) and not args.no_graph
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            mode = "hipGraph replay (one captured fwd+bwd step; wgrad kernels on a forked side stream)"
+        except Exception as e:  # noqa: BLE001 - fall back loudly, never silently
+            print("bench.py: hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
+            graph, mode = None, "eager (graph capture failed)"
+            torch.cuda.synchronize()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
+
     for _ in range(args.warmup):
-        step()
-    timer = None if args.no_kernel_timer else KernelTimer(ops, DOM)
+        run_step()
+    timer = None if (args.no_kernel_timer or graph is not None) else KernelTimer(ops, DOM)
     sync()
     t0 = time.perf_counter()
     if timer is not None:
         with timer:
             for _ in range(args.steps):
-                step()
+                run_step()
             sync()
             elapsed = time.perf_counter() - t0
     else:
         for _ in range(args.steps):
-            step()
+            run_step()
         sync()
         elapsed = time.perf_counter() - t0
+    timed_in = "the timed region"
+    if graph is not None and not args.no_kernel_timer:
+        # HIP events cannot be read back from inside a replayed graph: time the dominant launch in eager steps of
+        # the same process / tensors right after the timed region (same kernel, same stream, full-step context)
+        timer = KernelTimer(ops, DOM)
+        with timer:
+            for _ in range(min(args.steps, 5)):
+                step()
+            torch.cuda.synchronize()
+        timed_in = "eager steps right after the timed region (events cannot be read from a replayed graph)"
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -230,7 +268,7 @@ def main():
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "kernel": "conv_gemm_kernel<128,128,64> @ neck.fpn_convs.0 fwd (M=%d,N=256,K=2304)" %
                               (nimg * DOM["H"] * DOM["W"]),
-                    "avg_ms": round(ms, 4), "launches_timed": cnt}
+                    "avg_ms": round(ms, 4), "launches_timed": cnt, "timed_in": timed_in}
         line = {
             "metric": "images/sec ResNet-50-FPN fwd+bwd 1333x800" if args.depth == 50 else
                       "images/sec ResNet-%d-FPN fwd+bwd 1333x800" % args.depth,
@@ -242,7 +280,7 @@ def main():
                                    "cotangents, all parameter grads%s" %
                                    (args.depth, B, ", bucketed RCCL all-reduce (sum/%d) overlapped with backward"
                                     % world if world > 1 else ""),
-                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "execution": mode,
                        "mfma_frac_whole_step": round(mfma_frac, 4),
                        "algorithmic_gflop_per_image": FWDBWD_GFLOP[args.depth]},
             "roofline": roof,

@@ -5,6 +5,7 @@ There is no fallback: if the shared object is missing or a call fails, a Runtime
 """
 import ctypes
 import os
+import threading
 
 import torch  # noqa: F401  (loads the HIP runtime first so libtdn binds to the same libamdhip64)
 
@@ -99,6 +100,22 @@ def check(rc, what):
         raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
 
 
+_tls = threading.local()
+
+
 def stream_ptr():
-    """Raw hipStream_t of PyTorch's current stream (kernels are enqueued there)."""
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t the kernels are enqueued on: PyTorch's current stream, or the stream set by
+    ``use_stream`` for this thread (the weight-gradient side stream of functional.py)."""
+    ov = getattr(_tls, "stream", None)
+    if ov is not None:
+        return ov
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+def set_stream_override(raw_stream):
+    """Route this thread's kernel launches to ``raw_stream`` (int) until reset with ``None``.  Cheaper than
+    ``with torch.cuda.stream(...)`` (no allocator / current-stream switching); allocations stay on the current
+    PyTorch stream, so callers must order memory reuse themselves (``record_stream``)."""
+    prev = getattr(_tls, "stream", None)
+    _tls.stream = raw_stream
+    return prev

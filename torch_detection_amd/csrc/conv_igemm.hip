@@ -188,7 +188,70 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
   };
 
-  if (T > 0) {
+  if constexpr (MODE == 5) {
+    // Phase-staggered schedule for 8 waves = two groups of four (waves w and w+4 share a SIMD).  Every K-step is
+    // two phases separated by barriers; in each phase one group multiplies from REGISTER fragments while the other
+    // group reads its fragments of the current stage from LDS, so on every SIMD the matrix pipe and the LDS pipe
+    // always have a customer:
+    //     even phase 2u : all waves issue the LDS-DMA of stage u+1;  G0 reads stage u;   G1 multiplies stage u-1
+    //     odd  phase 2u+1:                                          G0 multiplies u;    G1 reads stage u
+    // Stage u+1 (slot (u+1)&1) was last read in odd phase 2u-1 and is needed again in even phase 2u+2: its DMA has
+    // two phases to land (every wave waits vmcnt(0) at the end of the odd phase, before the barrier).
+    static_assert(NSTAGE == 2 && WM == 2 && WN == 4, "staggered schedule: 2 LDS slots, 2x4 waves");
+    const bool g0 = wm == 0;
+    // one 32-deep sub-step per phase pair keeps the register fragments at (FM+FN) x 4 VGPRs
+    bf16x8_t wf[FN], xf[FM];
+    auto read_frags = [&](int slot, int kk) {
+      const char* sA = smem + slot * STAGE + (wm * WTM) * ROWB;
+      const char* sB = smem + slot * STAGE + A_BYTES + (wn * WTN) * ROWB;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) wf[i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[kk]);
+#pragma unroll
+      for (int j = 0; j < FM; ++j) xf[j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[kk]);
+    };
+    auto multiply = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    if (T > 0) {
+      stage_load(0);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      bool pending = false;   // G1 holds fragments that still have to be multiplied
+      for (int u = 0; u < T; ++u) {
+#pragma unroll
+        for (int kk = 0; kk < KSUB; ++kk) {
+          // ---- even phase: G0 reads sub-step (u, kk); G1 multiplies the previous sub-step ----
+          if (kk == 0 && u + 1 < T) stage_load((u + 1) & 1);
+          if (g0) {
+            read_frags(u & 1, kk);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          } else if (pending) {
+            multiply();
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_barrier" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- odd phase: G0 multiplies (u, kk); G1 reads it ----
+          if (g0) {
+            multiply();
+          } else {
+            read_frags(u & 1, kk);
+            pending = true;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk == KSUB - 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (!g0) multiply();
+    }
+  } else if (T > 0) {
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) stage_load(s);
     int slot = 0, fill = NSTAGE - 1;
@@ -205,6 +268,36 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
         for (int kk = 0; kk < KSUB; ++kk) mfma_substep(sA, sB, kk);
       } else if constexpr (MODE == 4) {   // ABLATION (timing only, wrong results): loads only, no LDS reads / MFMA
         stage_load(fill);
+      } else if constexpr (MODE == 6) {
+        // software-pipelined fragments: sub-step 1's LDS reads are issued between sub-step 0's MFMAs (second
+        // register set), so only ONE LDS latency per K-step is exposed; the interleave is pinned with
+        // sched_group_barrier (masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read)
+        static_assert(KSUB == 2, "pipelined-fragment schedule assumes BK = 64");
+        bf16x8_t wf[2][FN], xf[2][FM];
+#pragma unroll
+        for (int i = 0; i < FN; ++i) wf[0][i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[0]);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) xf[0][j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[0]);
+        stage_load(fill);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) wf[1][i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[1]);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) xf[1][j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[1]);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, FN + FM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, LOADS, 0);
+#pragma unroll
+        for (int r = 0; r < FN + FM; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x8, 2 * FN * FM - (FN + FM), 0);
       } else if constexpr (MODE == 2) {
         // all fragment reads of the K-step first (one exposed LDS latency per step instead of one per
         // read group), the LDS-DMA of the next step behind them, then the MFMAs
@@ -364,6 +457,16 @@ static const GemmCfg kCfgs[] = {
     {256, 128, 64, 4, 4, 2, 0},  // 52   96 KB, 1024 thr, wave tile 64x32
     {256, 256, 64, 4, 4, 2, 4},  // 53  loads only
     {256, 256, 64, 4, 4, 2, 3},  // 54  compute only
+    {192, 256, 64, 2, 4, 2, 5},  // 55  phase-staggered wave groups
+    {256, 256, 64, 2, 4, 2, 5},  // 56
+    {128, 256, 64, 2, 4, 2, 5},  // 57
+    {128, 128, 64, 2, 4, 2, 5},  // 58
+    {256, 128, 64, 2, 4, 2, 5},  // 59
+    {64, 128, 64, 2, 4, 2, 5},   // 60  wave tile 32x32
+    {192, 256, 64, 2, 4, 2, 6},  // 61  pipelined fragments
+    {64, 128, 64, 2, 2, 2, 6},   // 62
+    {128, 128, 64, 2, 2, 2, 6},  // 63
+    {256, 128, 64, 4, 2, 3, 6},  // 64
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -375,11 +478,11 @@ static int choose_cfg(int maxM, int ngemm) {
   // Measured on MI355X over the R50-FPN shapes (scripts/conv_bench.py; profiles/convbench_*.log): several small
   // co-resident workgroups per CU (64-pixel tiles, 2-deep ring, 32-48 KB LDS) beat one large deeply pipelined
   // workgroup on almost every shape; only the very large-M 3x3 convs prefer the 256x128 8-wave tile.
-  if (ngemm % 256 == 0 && maxM >= 24000) return 34;   // 192x256, 8 waves: fewest L2->LDS bytes per flop
+  if (ngemm % 256 == 0 && maxM >= 24000) return 61;   // 192x256, 8 waves: fewest L2->LDS bytes per flop
   if (ngemm % 128 == 0) {
-    if (maxM >= 100000) return 14;
+    if (maxM >= 100000) return 63;
     const long t64 = (long)ceil_div(maxM, 64) * (ngemm / 128);
-    return t64 >= 300 ? 17 : 19;
+    return t64 >= 300 ? 62 : 19;
   }
   return 19;
 }
@@ -460,7 +563,17 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
     case 51: return launch_gemm<128, 256, 64, 2, 8, 2, 0>(p, maxM, stream);
     case 52: return launch_gemm<256, 128, 64, 4, 4, 2, 0>(p, maxM, stream);
     case 53: return launch_gemm<256, 256, 64, 4, 4, 2, 4>(p, maxM, stream);
-    default: return launch_gemm<256, 256, 64, 4, 4, 2, 3>(p, maxM, stream);
+    case 54: return launch_gemm<256, 256, 64, 4, 4, 2, 3>(p, maxM, stream);
+    case 55: return launch_gemm<192, 256, 64, 2, 4, 2, 5>(p, maxM, stream);
+    case 56: return launch_gemm<256, 256, 64, 2, 4, 2, 5>(p, maxM, stream);
+    case 57: return launch_gemm<128, 256, 64, 2, 4, 2, 5>(p, maxM, stream);
+    case 58: return launch_gemm<128, 128, 64, 2, 4, 2, 5>(p, maxM, stream);
+    case 59: return launch_gemm<256, 128, 64, 2, 4, 2, 5>(p, maxM, stream);
+    case 60: return launch_gemm<64, 128, 64, 2, 4, 2, 5>(p, maxM, stream);
+    case 61: return launch_gemm<192, 256, 64, 2, 4, 2, 6>(p, maxM, stream);
+    case 62: return launch_gemm<64, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
+    case 63: return launch_gemm<128, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
+    default: return launch_gemm<256, 128, 64, 4, 2, 3, 6>(p, maxM, stream);
   }
 }
 

@@ -300,7 +300,15 @@ struct WgradPlan { int bmw, bnw, tiles_co, tiles_k, splitk, mchunk, M, Ktot; };
 static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps) {
   WgradPlan w;
   w.bmw = (Cout % 128 == 0) ? 128 : 64;
-  w.bnw = (Ktap % 128 == 0) ? 128 : (Ktap % 64 == 0 ? 64 : 32);
+  w.bnw = (Ktap % 64 == 0) ? 64 : 32;   // 128x64 measured ~4% faster over the whole step than 128x128
+  if (const char* env = getenv("TDN_WGRAD_TILE")) {   // tuning override: "BMWxBNW" with 64/128 entries
+    int a = 0, b = 0;
+    if (sscanf(env, "%dx%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 64 || b == 128) && Cout % a == 0 &&
+        Ktap % b == 0) {
+      w.bmw = a;
+      w.bnw = b;
+    }
+  }
   w.tiles_co = Cout / w.bmw;
   w.tiles_k = ntaps * (Ktap / w.bnw);
   w.M = M;
@@ -309,7 +317,7 @@ static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps) {
   // Aim for ~512 workgroups (two 64 KB-LDS workgroups fit a CU) but keep each split >= 1024 pixels deep: every
   // workgroup writes a full fp32 tile slab, so short splits turn the kernel (and the finalize pass that re-reads
   // the slabs) into an HBM-bound slab copy.
-  int target = 512, min_chunk = 1024;
+  int target = 512, min_chunk = 512;
   if (const char* env = getenv("TDN_WGRAD_WGS")) target = atoi(env) > 0 ? atoi(env) : target;
   if (const char* env = getenv("TDN_WGRAD_MINCHUNK")) min_chunk = atoi(env) > 0 ? atoi(env) : min_chunk;
   int splitk = ceil_div(target, tiles);

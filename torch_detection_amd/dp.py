@@ -59,23 +59,26 @@ class GradReducer(object):
         self._pending = [b[2] for b in self.buckets]
         self._works = []
 
-    def mark_ready(self, slot):
-        """Slot's gradient has been enqueued on the current stream; launch its bucket's all-reduce if complete."""
+    def mark_ready(self, slot, stream=None):
+        """Slot's gradient has been enqueued on ``stream`` (default: the current stream); launch its bucket's
+        all-reduce if complete."""
         b = self.bucket_of[slot]
         self._pending[b] -= 1
         if self._pending[b] == 0:
-            self._launch(b)
+            self._launch(b, stream)
         elif self._pending[b] < 0:
             raise RuntimeError('GradReducer: slot %d marked ready twice in one step (call reset()/finish())' % slot)
 
-    def _launch(self, b):
+    def _launch(self, b, stream=None):
         start, end, _ = self.buckets[b]
         buf = self.flat[start:end]
         if not self.enabled:
             return
         if self.use_streams:
+            # every gradient of the bucket was produced on `stream` (the wgrad side stream) or, when a bucket is
+            # flushed from finish(), on streams the current stream has already joined
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+            ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -139,9 +142,9 @@ def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True):
         u.sink = (views[0].view(w.shape) if u.is_stem else views[0], views[1] if len(ps) > 1 else None,
                   views[2] if len(ps) > 2 else None)
 
-        def _cb(unit, _slots=slots, _red=red):
+        def _cb(unit, stream=None, _slots=slots, _red=red):
             for s in _slots:
-                _red.mark_ready(s)
+                _red.mark_ready(s, stream)
         u.on_grads = _cb
     return red
 

@@ -13,10 +13,13 @@ ResNet.forward resnet.py:253-268, ConvModule.forward layers.py:122-135, FPN.forw
 BN is folded as the per-channel affine the reference's default ``bn_eval=True`` makes it (resnet.py:270-276);
 its gamma/beta still get gradients (``bn_frozen=False``).
 """
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .ops import ADD_NONE, ADD_SAME, ADD_SUMPOOL2, ADD_UP2X
 
 # Test instrumentation: when set to a dict, the forward passes drop references to the tensors they save for
@@ -143,28 +146,75 @@ def unit_dgrad(u, g, in_hw, addend=None, addend_mode=ADD_NONE, mask_src=None):
     return ops.conv2d_dgrad(g, u.w_dgrad, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
 
 
+# Weight-gradient kernels run on a side HIP stream: within a backward pass they depend only on tensors that
+# already exist (the saved forward input and the activation gradient g), while the dgrad chain that produces the
+# next g is the critical path.  Most per-layer launches of this network cannot fill 256 CUs on their own, so
+# letting wgrad(l) overlap dgrad(l), dgrad(l-1), ... recovers idle CUs.  TDN_SIDE_STREAM=0 disables it.
+_side_streams = {}
+
+
+def _side_stream(device):
+    if os.environ.get('TDN_SIDE_STREAM', '1') == '0':
+        return None
+    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index))
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
+def join_side_stream(device):
+    """Make the current stream wait for the side stream's weight-gradient kernels (end of a backward pass)."""
+    st = _side_streams.get((device.index, torch._C._cuda_getCurrentRawStream(device.index)))
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
+
+
 def unit_wgrad(u, x_in, g, img_hw=None):
     """Gradients aligned with ``u.params()``.  With a gradient sink attached (dp.py) the kernels write straight
     into the bucket views and ``None`` is returned for autograd (``param.grad`` already aliases the views)."""
     sink = u.sink
-    dw = dg = db = None
+    dev = g.device
+    dg = db = None
     if sink is not None:
         dw, d0, d1 = sink
         if u.bn is not None:
             dg, db = d0, d1
         else:
             db = d0
-    if u.is_stem:
-        dw, dg, db = ops.stem_conv_wgrad(x_in, g, u.w_fwd, img_hw, u.scale, u.mean, u.invstd, dw, dg, db)
-        dw_view = dw
     else:
-        dw4 = dw.view(u.Cout, u.k, u.k, u.Cin) if dw is not None else None
-        dw4, dg, db = ops.conv2d_wgrad(x_in, g, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.mean, u.invstd, dw4, dg, db)
-        # 1x1: [Cout,1,1,Cin] is byte-identical to the contiguous OIHW parameter -> view, so autograd's
-        # layout contract holds and AccumulateGrad does not copy
-        dw_view = dw4.view(u.Cout, u.Cin, 1, 1) if u.k == 1 else dw4.permute(0, 3, 1, 2)
+        # outputs are allocated on the main stream (their consumers live there); only the kernels move
+        dw = torch.empty((u.Cout, 3, 7, 7) if u.is_stem else (u.Cout, u.k, u.k, u.Cin), dtype=torch.float32, device=dev)
+        if u.bn is not None:
+            dg = torch.empty(u.Cout, dtype=torch.float32, device=dev)
+        if u.bn is not None or u.conv.bias is not None:
+            db = torch.empty(u.Cout, dtype=torch.float32, device=dev)
+    side = _side_stream(dev)
+    prev = None
+    if side is not None:
+        ev = torch.cuda.Event()
+        ev.record()               # g (and everything before it) is ready on the main stream
+        side.wait_event(ev)
+        for t in (x_in, g):       # keep their memory from being recycled while the side stream still reads it
+            t.record_stream(side)
+        prev = _lib.set_stream_override(side.cuda_stream)
+    try:
+        if u.is_stem:
+            dw, dg, db = ops.stem_conv_wgrad(x_in, g, u.w_fwd, img_hw, u.scale, u.mean, u.invstd, dw, dg, db)
+            dw_view = dw
+        else:
+            dw4 = dw.view(u.Cout, u.k, u.k, u.Cin)
+            dw4, dg, db = ops.conv2d_wgrad(x_in, g, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.mean, u.invstd, dw4,
+                                           dg, db)
+            # 1x1: [Cout,1,1,Cin] is byte-identical to the contiguous OIHW parameter -> view, so autograd's
+            # layout contract holds and AccumulateGrad does not copy
+            dw_view = dw4.view(u.Cout, u.Cin, 1, 1) if u.k == 1 else dw4.permute(0, 3, 1, 2)
+    finally:
+        if side is not None:
+            _lib.set_stream_override(prev)
     if u.on_grads is not None:
-        u.on_grads(u)
+        u.on_grads(u, side)
     if sink is not None:
         return [None] * len(u.params())
     if u.bn is not None:
@@ -195,6 +245,7 @@ class ConvUnitFunction(torch.autograd.Function):
             g = ops.add_relu_mask(g, None, ctx.y)
         grads = unit_wgrad(u, ctx.xh, g)
         dx = _as_nchw(unit_dgrad(u, g, _hw(ctx.xh))) if ctx.needs_input_grad[1] else None
+        join_side_stream(g.device)
         return (None, dx) + tuple(grads)
 
 
@@ -298,7 +349,7 @@ class SeqNetFunction(torch.autograd.Function):
                 outs.append(cur)
         if not net.blocks:
             outs.append(cur)
-        ctx.net, ctx.st, ctx.saved = net, st, saved
+        ctx.net, ctx.st, ctx.saved, ctx.dev = net, st, saved, cur.device
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE['seq'] = (st, saved)
         return tuple(_as_nchw(o) for o in outs)
@@ -337,6 +388,7 @@ class SeqNetFunction(torch.autograd.Function):
         flat = []
         for u in net.units():
             flat += unit_grads.get(u, [None] * len(u.params()))
+        join_side_stream(ctx.dev)
         return (None, dx_in) + tuple(flat)
 
 
@@ -440,4 +492,5 @@ class FPNFunction(torch.autograd.Function):
         flat = []
         for u in net.units():
             flat += unit_grads.get(u, [None] * len(u.params()))
+        join_side_stream(dev)
         return (None,) + tuple(_as_nchw(t) if t is not None else None for t in dx) + tuple(flat)

@@ -141,7 +141,7 @@ _ws_cache = {}
 
 def _workspace(nbytes, device):
     """One grow-only scratch buffer per device; all users are ordered on the current stream."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _lib.stream_ptr())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
