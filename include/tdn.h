@@ -186,6 +186,14 @@ int tdn_nms(const float* boxes, const float* scores, int N, float iou_thr, uint8
             int64_t* kept_idx, int32_t* num_kept, void* workspace, int64_t workspace_bytes,
             void* stream);
 
+/* Box delta (de)normalisation (reference: datasets/utils/bbox.py:118-166).
+ *   normalize:   bbox[rows][4] <- (bbox - means) / stds, IN PLACE like `bbox.sub_(means).div_(stds)` (bbox.py:140)
+ *   denormalize: out[rows][cols] = bbox * stds + means, means/stds tiled over cols = 4C (bbox.py:161-165)
+ * means4 / stds4 are HOST arrays of 4 floats. Separate IEEE sub/div and mul/add: bit-identical to PyTorch-CPU. */
+int tdn_bbox_normalize(float* bbox, int64_t rows, const float* means4, const float* stds4, void* stream);
+int tdn_bbox_denormalize(const float* bbox, float* out, int64_t rows, int cols, const float* means4,
+                         const float* stds4, void* stream);
+
 /* ---- host-only introspection (no GPU needed; used by CPU tests) --------------------- */
 
 /* Describes the GEMM decomposition the library would launch for a conv: fills out[0..15] with

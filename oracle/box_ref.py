@@ -136,3 +136,23 @@ def py_nms(boxes, scores, thr):
             if not dead[j] and iou[i, j] > np.float32(thr):
                 dead[j] = True
     return keep, np.asarray(kept, dtype=np.int64)
+
+
+# ---- box delta (de)normalisation: restatement of /root/reference/datasets/utils/bbox.py:118-166 ----------------
+# PINNED by golden vectors captured from the reference functions themselves (tests/golden/bbox_norm.npz,
+# oracle/gen_golden.py).
+def np_bbox_normalize(bbox, means=(0, 0, 0, 0), stds=(1., 1., 1., 1.)):
+    """bbox.sub_(means).div_(stds) (bbox.py:136-140); returns a new array (the reference works in place)."""
+    b = np.asarray(bbox, dtype=np.float32)
+    assert b.shape[1] == 4
+    return (b - np.asarray(means, dtype=np.float32)[None, :]) / np.asarray(stds, dtype=np.float32)[None, :]
+
+
+def np_bbox_denormalize(bbox, means=(0, 0, 0, 0), stds=(1., 1., 1., 1.)):
+    """bbox * stds + means with means/stds tiled over 4C columns (bbox.py:157-166)."""
+    b = np.asarray(bbox, dtype=np.float32)
+    assert b.shape[1] % 4 == 0
+    rep = b.shape[1] // 4
+    m = np.tile(np.asarray(means, dtype=np.float32), rep)[None, :]
+    s = np.tile(np.asarray(stds, dtype=np.float32), rep)[None, :]
+    return b * s + m

@@ -200,6 +200,62 @@ def main():
     except AssertionError:
         man["fpn_wrong_len_error"] = "AssertionError"
 
+    # ---- PAFPN: fwd + input grads + param grads, with and without ReLU -------------
+    RefPAFPN = NECKS.module_dict["PAFPN"]
+    man["pafpn_keys"] = manifest_of(RefPAFPN(chans, 64, 5))
+    pf = {}
+    for tag, actv in (("none", None), ("relu", "relu")):
+        pa = RefPAFPN(chans, 64, 5, activation=actv)
+        sdp = fill_state_dict(pa.state_dict(), 800)
+        pa.load_state_dict(sdp)
+        pins = [det_tensor((2, c, h, w), 810 + i, -1.0, 1.0).requires_grad_(True) for i, (c, (h, w)) in
+                enumerate(zip(chans, sizes))]
+        pouts = pa(pins)
+        pcots = [det_tensor(tuple(o.shape), 820 + i, -1.0, 1.0) for i, o in enumerate(pouts)]
+        torch.autograd.backward(pouts, pcots)
+        pps = {k: v.detach().clone().requires_grad_(True) for k, v in sdp.items()}
+        pins2 = [t.detach().clone().requires_grad_(True) for t in pins]
+        pouts2 = O.pafpn_forward(pps, pins2, 5, actv)
+        torch.autograd.backward(pouts2, pcots)
+        for a, b in zip(pouts, pouts2):
+            assert torch.equal(a, b), "oracle != reference (PAFPN forward %s)" % tag
+        for a, b in zip(pins, pins2):
+            assert torch.equal(a.grad, b.grad), "oracle != reference (PAFPN input grad %s)" % tag
+        for k, p in pa.named_parameters():
+            assert torch.equal(pps[k].grad, p.grad), "oracle != reference (PAFPN grad %s %s)" % (tag, k)
+        for i, o in enumerate(pouts):
+            pf["%s/out%d" % (tag, i)] = o.detach().numpy().astype(np.float16 if False else np.float32)
+        for i, t in enumerate(pins):
+            pf["%s/din%d" % (tag, i)] = t.grad.numpy()
+        for k, p in pa.named_parameters():
+            if k.startswith("pa_convs") or tag == "none":
+                pf["%s/grad/%s" % (tag, k)] = p.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, "pafpn.npz"), **pf)
+    man["pafpn_small"] = {"in_channels": chans, "out_channels": 64, "num_outs": 5, "sizes": [list(s) for s in sizes],
+                          "N": 2, "state_seed": 800, "in_seed0": 810, "cot_seed0": 820}
+
+    # ---- box delta (de)normalisation: the reference's own functions ---------------
+    from datasets.utils.bbox import bbox_denormalize as ref_denorm, bbox_normalize as ref_norm
+    from oracle import box_ref as BR
+    means, stds = [0.0, 0.0, 0.0, 0.0], [0.1, 0.1, 0.2, 0.2]
+    means2, stds2 = [0.5, -0.25, 0.125, 1.0], [0.3, 0.7, 1.1, 0.9]
+    b4 = det_tensor((257, 4), 900, -3.0, 3.0, bf16=False)
+    b12 = det_tensor((65, 12), 901, -3.0, 3.0, bf16=False)
+    bn = {}
+    for tag, (m, s) in (("a", (means, stds)), ("b", (means2, stds2))):
+        n = ref_norm(b4.clone(), m, s)
+        d4 = ref_denorm(b4.clone(), m, s)
+        d12 = ref_denorm(b12.clone(), m, s)
+        assert np.array_equal(n.numpy(), BR.np_bbox_normalize(b4.numpy(), m, s)), "oracle != reference (bbox_normalize)"
+        assert np.array_equal(d4.numpy(), BR.np_bbox_denormalize(b4.numpy(), m, s))
+        assert np.array_equal(d12.numpy(), BR.np_bbox_denormalize(b12.numpy(), m, s))
+        bn[tag + "/norm"], bn[tag + "/denorm4"], bn[tag + "/denorm12"] = n.numpy(), d4.numpy(), d12.numpy()
+    t = b4.clone()
+    assert ref_norm(t, means, stds) is t      # in-place contract (bbox.py:140)
+    np.savez_compressed(os.path.join(GOLD, "bbox_norm.npz"), **bn)
+    man["bbox_norm"] = {"seed4": 900, "seed12": 901, "lo": -3.0, "hi": 3.0,
+                        "a": [means, stds], "b": [means2, stds2], "normalize_in_place": True}
+
     # ---- R50+FPN end-to-end fwd+bwd oracle == reference (small, not stored) ----------------------
     rb = RefResNet(50)
     rf = RefFPN([256, 512, 1024, 2048], 256, 5)

@@ -195,3 +195,34 @@ def test_weight_update_is_picked_up(T):
         blk.conv.bias.zero_()
         y1 = blk(x)
     assert not torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("tag,actv", [("none", None), ("relu", "relu")])
+def test_pafpn_vs_golden(T, manifest, golden_dir, tag, actv):
+    """PAFPN on the HIP path vs vectors captured from the reference import."""
+    meta = manifest["pafpn_small"]
+    gold = np.load(os.path.join(golden_dir, "pafpn.npz"))
+    mod = T.PAFPN(meta["in_channels"], meta["out_channels"], meta["num_outs"], activation=actv)
+    mod.load_state_dict(fill_state_dict(mod.state_dict(), meta["state_seed"]))
+    mod.cuda()
+    ins = [det_tensor((meta["N"], c, h, w), meta["in_seed0"] + i, -1, 1).cuda().requires_grad_(True)
+           for i, (c, (h, w)) in enumerate(zip(meta["in_channels"], meta["sizes"]))]
+    outs = mod(ins)
+    assert len(outs) == meta["num_outs"]
+    cots = [det_tensor(tuple(o.shape), meta["cot_seed0"] + i, -1, 1).cuda().to(o.dtype) for i, o in enumerate(outs)]
+    torch.autograd.backward(outs, cots)
+    eo = [rel_l2(_f32(o), torch.from_numpy(gold["%s/out%d" % (tag, i)])) for i, o in enumerate(outs)]
+    ei = [rel_l2(_f32(t.grad), torch.from_numpy(gold["%s/din%d" % (tag, i)])) for i, t in enumerate(ins)]
+    eg = {}
+    for k, p in mod.named_parameters():
+        key = "%s/grad/%s" % (tag, k)
+        if key in gold.files:
+            eg[k] = rel_l2(_f32(p.grad), torch.from_numpy(gold[key]))
+    _record("pafpn_small/" + tag, {"out": eo, "din": ei, "grad_max": max(eg.values())})
+    assert max(eo) <= 8e-3, eo
+    # without an activation the path is linear: tight.  With ReLU the masks of tiny maps (2x3 .. 16x24) flip on a
+    # visible fraction of elements (module docstring): measured 3e-2 .. 1.3e-1, bound 2.5e-1 (a routing bug is O(1)
+    # and is already excluded by the linear case, which shares all the code but the masks)
+    tol = 1.5e-2 if actv is None else 2.5e-1
+    assert max(ei) <= tol, ei
+    assert max(eg.values()) <= tol, eg

@@ -68,3 +68,21 @@ def test_nms_known_answers():
     k1, kk1, c = B.nms(b, s, 0.5)
     k2, kk2 = B.py_nms(b, s, 0.5)
     assert np.array_equal(k1, k2) and np.array_equal(kk1[:c], kk2)
+
+
+def test_bbox_norm_oracle_vs_reference_golden(golden_dir=None):
+    """Box delta (de)normalisation: the numpy restatement reproduces vectors captured from the reference's own
+    datasets/utils/bbox.py:118-166 bit for bit (this row IS pinned by the reference)."""
+    import json
+    import os
+    from golden_util import det_tensor
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    man = json.load(open(os.path.join(gd, "manifest.json")))["bbox_norm"]
+    gold = np.load(os.path.join(gd, "bbox_norm.npz"))
+    b4 = det_tensor((257, 4), man["seed4"], man["lo"], man["hi"], bf16=False).numpy()
+    b12 = det_tensor((65, 12), man["seed12"], man["lo"], man["hi"], bf16=False).numpy()
+    for tag in ("a", "b"):
+        m, s = man[tag]
+        assert np.array_equal(B.np_bbox_normalize(b4, m, s), gold[tag + "/norm"])
+        assert np.array_equal(B.np_bbox_denormalize(b4, m, s), gold[tag + "/denorm4"])
+        assert np.array_equal(B.np_bbox_denormalize(b12, m, s), gold[tag + "/denorm12"])

@@ -69,6 +69,7 @@ def test_fpn_oracle_bit_exact(manifest, golden_dir):
     from oracle import torch_ref as O
     meta = manifest["fpn_small"]
     gold = np.load(os.path.join(golden_dir, "fpn.npz"))
+    torch.set_num_threads(4)   # bit-exactness of CPU reductions depends on the thread count the fixtures used
     sd = fill_state_dict(T.FPN(meta["in_channels"], meta["out_channels"], meta["num_outs"]).state_dict(),
                          meta["state_seed"])
     ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
@@ -90,6 +91,7 @@ def test_block_oracle_bit_exact(manifest, golden_dir):
     import torch_detection_amd as T
     from torch_detection_amd.backbone.resnet import _make_res_layer
     gold = np.load(os.path.join(golden_dir, "blocks.npz"))
+    torch.set_num_threads(4)
     for name, meta in sorted(manifest["blocks"].items()):
         cls = getattr(T, meta["cls"])
         blk = _make_res_layer(cls, meta["inplanes"], meta["planes"], 1, stride=meta["stride"])[0]
@@ -135,3 +137,30 @@ def test_constructor_and_registry_semantics(manifest):
     # non-hot-path configurations are constructible (checkpoints stay inspectable) but refuse to run silently
     g = T.ResNet(18, use_gn=True)
     assert "gn1.weight" in g.state_dict()
+
+
+@pytest.mark.parametrize("tag,actv", [("none", None), ("relu", "relu")])
+def test_pafpn_oracle_bit_exact(manifest, golden_dir, tag, actv):
+    """PAFPN (models/necks/pafpn.py:103-148)."""
+    import torch_detection_amd as T
+    from oracle import torch_ref as O
+    meta = manifest["pafpn_small"]
+    gold = np.load(os.path.join(golden_dir, "pafpn.npz"))
+    torch.set_num_threads(4)   # bit-exactness of CPU reductions depends on the thread count the fixtures used
+    mod = T.PAFPN(meta["in_channels"], meta["out_channels"], meta["num_outs"], activation=actv)
+    assert _keys(mod) == manifest["pafpn_keys"]
+    sd = fill_state_dict(mod.state_dict(), meta["state_seed"])
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ins = [det_tensor((meta["N"], c, h, w), meta["in_seed0"] + i, -1, 1).requires_grad_(True)
+           for i, (c, (h, w)) in enumerate(zip(meta["in_channels"], meta["sizes"]))]
+    outs = O.pafpn_forward(ps, ins, meta["num_outs"], actv)
+    cots = [det_tensor(tuple(o.shape), meta["cot_seed0"] + i, -1, 1) for i, o in enumerate(outs)]
+    torch.autograd.backward(outs, cots)
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.detach().numpy(), gold["%s/out%d" % (tag, i)])
+    for i, t in enumerate(ins):
+        assert np.array_equal(t.grad.numpy(), gold["%s/din%d" % (tag, i)])
+    for k, p in ps.items():
+        key = "%s/grad/%s" % (tag, k)
+        if key in gold:
+            assert np.array_equal(p.grad.numpy(), gold[key]), k

@@ -13,5 +13,6 @@ from .inits import (bias_init_with_prob, constant_init, kaiming_init, normal_ini
                     xavier_init)
 from .checkpoint import load_checkpoint, load_state_dict, save_checkpoint  # noqa: F401
 from .backbone import BasicBlock, Bottleneck, ResNet  # noqa: F401
-from .necks import FPN  # noqa: F401
-from .box import AnchorGenerator, bbox_overlaps, nms, nms_mask  # noqa: F401
+from .necks import FPN, PAFPN  # noqa: F401
+from .box import (AnchorGenerator, bbox_denormalize, bbox_normalize, bbox_overlaps, nms,  # noqa: F401
+                  nms_mask)

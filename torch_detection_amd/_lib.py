@@ -69,6 +69,9 @@ SIGNATURES = {
     "tdn_nms_workspace": (c_i64, [c_int]),
     "tdn_nms": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
                         c_void_p]),
+    "tdn_bbox_normalize": (c_int, [c_void_p, c_i64, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
+    "tdn_bbox_denormalize": (c_int, [c_void_p, c_void_p, c_i64, c_int, ctypes.POINTER(c_float),
+                                     ctypes.POINTER(c_float), c_void_p]),
     "tdn_conv2d_plan": (c_int, [c_int] * 9 + [ctypes.POINTER(ctypes.c_int32)]),
 }
 

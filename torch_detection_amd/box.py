@@ -87,6 +87,22 @@ def nms(dets, iou_thr):
     return full[inds], inds
 
 
+def bbox_normalize(bbox, means=[0, 0, 0, 0], stds=[1., 1., 1., 1.]):
+    """Normalise box deltas by means / stds — same name, arguments and IN-PLACE behaviour as the reference's
+    ``datasets/utils/bbox.py:118-140`` (``bbox.sub_(means).div_(stds)``; the input tensor is modified and returned).
+    Bit-identical to the reference on the same input (golden vectors: tests/golden/bbox_norm.npz)."""
+    assert bbox.shape[1] == len(means) == len(stds) == 4
+    return ops.bbox_normalize_(bbox, means, stds)
+
+
+def bbox_denormalize(bbox, means=[0, 0, 0, 0], stds=[1., 1., 1., 1.]):
+    """De-normalise (A, 4) or class-specific (A, 4C) deltas: ``bbox * stds + means`` —
+    ``datasets/utils/bbox.py:143-166``.  Returns a new tensor (the reference does too: it needs the graph)."""
+    assert bbox.shape[1] % 4 == 0
+    assert len(means) == len(stds) == 4
+    return ops.bbox_denormalize(bbox.contiguous(), means, stds)
+
+
 def nms_mask(boxes, scores, iou_thr):
     """(keep uint8 (N,) in input order, kept indices int64 (N,) in score order padded with -1, count int32 (1,))
     without any host synchronisation."""

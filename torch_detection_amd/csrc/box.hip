@@ -256,3 +256,53 @@ extern "C" int tdn_nms(const float* boxes, const float* scores, int N, float iou
   TDN_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- box delta (de)normalisation: datasets/utils/bbox.py:118-166 of the reference --------------------------
+// normalize: bbox <- (bbox - means) / stds, IN PLACE like the reference (bbox.sub_(means).div_(stds), bbox.py:140);
+// denormalize: out = bbox * stds + means with means/stds tiled over the 4C columns (bbox.py:161-165).
+// Separate IEEE sub/div and mul/add (no FMA) so results are bit-identical to the PyTorch-CPU reference.
+__global__ void bbox_normalize_kernel(float* bbox, int64_t n4, f32x4_t means, f32x4_t stds) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4_t v = *(f32x4_t*)(bbox + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __fdiv_rn(__fsub_rn(v[e], means[e]), stds[e]);
+    *(f32x4_t*)(bbox + i * 4) = v;
+  }
+}
+
+__global__ void bbox_denormalize_kernel(const float* __restrict__ bbox, float* __restrict__ out, int64_t n4,
+                                        f32x4_t means, f32x4_t stds) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4_t v = *(const f32x4_t*)(bbox + i * 4);
+    f32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn(v[e], stds[e]), means[e]);
+    *(f32x4_t*)(out + i * 4) = o;
+  }
+}
+
+extern "C" int tdn_bbox_normalize(float* bbox, int64_t rows, const float* means4, const float* stds4, void* stream) {
+  TDN_CHECK(rows >= 0 && means4 && stds4, "tdn_bbox_normalize: bad arguments");
+  if (rows == 0) return 0;
+  TDN_CHECK(bbox != nullptr, "tdn_bbox_normalize: NULL bbox");
+  const f32x4_t m = {means4[0], means4[1], means4[2], means4[3]}, s = {stds4[0], stds4[1], stds4[2], stds4[3]};
+  int64_t grid = (rows + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(bbox_normalize_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, bbox, rows, m, s);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tdn_bbox_denormalize(const float* bbox, float* out, int64_t rows, int cols, const float* means4,
+                                    const float* stds4, void* stream) {
+  TDN_CHECK(rows >= 0 && cols > 0 && cols % 4 == 0 && means4 && stds4, "tdn_bbox_denormalize: cols must be 4C");
+  const int64_t n4 = rows * (cols / 4);
+  if (n4 == 0) return 0;
+  TDN_CHECK(bbox && out, "tdn_bbox_denormalize: NULL pointer");
+  const f32x4_t m = {means4[0], means4[1], means4[2], means4[3]}, s = {stds4[0], stds4[1], stds4[2], stds4[3]};
+  int64_t grid = (n4 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(bbox_denormalize_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, bbox, out, n4, m, s);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}

@@ -151,24 +151,35 @@ def unit_dgrad(u, g, in_hw, addend=None, addend_mode=ADD_NONE, mask_src=None):
 # next g is the critical path.  Most per-layer launches of this network cannot fill 256 CUs on their own, so
 # letting wgrad(l) overlap dgrad(l), dgrad(l-1), ... recovers idle CUs.  TDN_SIDE_STREAM=0 disables it.
 _side_streams = {}
+_side_rr = [0]
+
+
+def _num_side_streams():
+    return max(0, int(os.environ.get('TDN_SIDE_STREAM', '4')))
 
 
 def _side_stream(device):
-    if os.environ.get('TDN_SIDE_STREAM', '1') == '0':
+    """Next side stream (round robin over TDN_SIDE_STREAM streams, default 4; 0 disables) for this device /
+    main stream."""
+    n = _num_side_streams()
+    if n == 0:
         return None
     key = (device.index, torch._C._cuda_getCurrentRawStream(device.index))
-    st = _side_streams.get(key)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _side_streams[key] = st
-    return st
+    pool = _side_streams.get(key)
+    if pool is None or len(pool) != n:
+        pool = [torch.cuda.Stream(device=device) for _ in range(n)]
+        _side_streams[key] = pool
+    _side_rr[0] = (_side_rr[0] + 1) % n
+    return pool[_side_rr[0]]
 
 
 def join_side_stream(device):
-    """Make the current stream wait for the side stream's weight-gradient kernels (end of a backward pass)."""
-    st = _side_streams.get((device.index, torch._C._cuda_getCurrentRawStream(device.index)))
-    if st is not None:
-        torch.cuda.current_stream(device).wait_stream(st)
+    """Make the current stream wait for the side streams' weight-gradient kernels (end of a backward pass)."""
+    pool = _side_streams.get((device.index, torch._C._cuda_getCurrentRawStream(device.index)))
+    if pool:
+        cur = torch.cuda.current_stream(device)
+        for st in pool:
+            cur.wait_stream(st)
 
 
 def unit_wgrad(u, x_in, g, img_hw=None):
@@ -494,3 +505,78 @@ class FPNFunction(torch.autograd.Function):
             flat += unit_grads.get(u, [None] * len(u.params()))
         join_side_stream(dev)
         return (None,) + tuple(_as_nchw(t) if t is not None else None for t in dx) + tuple(flat)
+
+
+# ---------------------------------------------------------------------------------------------------
+# PAFPN bottom-up path (pafpn.py:127-131) + stride-2 extra levels (pafpn.py:136-138)
+# ---------------------------------------------------------------------------------------------------
+class PAPathNet(object):
+    def __init__(self, pa1, pa2, num_extra):
+        self.pa1, self.pa2, self.num_extra = pa1, pa2, num_extra
+
+    def units(self):
+        us = []
+        for a, b in zip(self.pa1, self.pa2):
+            us += [a, b]
+        return us
+
+    def params(self):
+        ps = []
+        for u in self.units():
+            ps += u.params()
+        return ps
+
+
+class PAPathFunction(torch.autograd.Function):
+    """N_0 = P_0;  N_i = pa_convs2[i-1](P_i + pa_convs1[i-1](N_{i-1}))  (pafpn.py:129-131), then
+    ``num_extra`` levels by stride-2 subsampling of the last one.  Without an activation the ``P_i +`` is fused
+    into the stride-2 conv's epilogue; with ReLU (which acts before the add) it is a separate add kernel."""
+
+    @staticmethod
+    def forward(ctx, net, *args):
+        n = len(net.pa1) + 1
+        P = [ops.to_nhwc_bf16(t) for t in args[:n]]
+        outs, t_saved, s_saved = [P[0]], [], []
+        for i in range(1, n):
+            u1, u2 = net.pa1[i - 1], net.pa2[i - 1]
+            if u1.relu:
+                t = unit_fwd(u1, outs[i - 1])
+                s_in = ops.add_relu_mask(t, P[i], None)
+            else:
+                t = None
+                s_in = unit_fwd(u1, outs[i - 1], P[i], ADD_SAME)
+            t_saved.append(t)
+            s_saved.append(s_in)
+            outs.append(unit_fwd(u2, s_in))
+        for _ in range(net.num_extra):
+            outs.append(ops.subsample2_fwd(outs[-1]))
+        ctx.net, ctx.outs, ctx.t_saved, ctx.s_saved, ctx.n = net, outs, t_saved, s_saved, n
+        return tuple(_as_nchw(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        net, outs, n = ctx.net, ctx.outs, ctx.n
+        dev = outs[0].device
+        d = [ops.to_nhwc_bf16(t) if t is not None else None for t in douts]
+        for j in range(len(outs) - 1, n - 1, -1):       # fold the subsampled extra levels back
+            if d[j] is not None:
+                d[j - 1] = ops.subsample2_bwd(d[j], _hw(outs[j - 1]), d[j - 1])
+        unit_grads = {}
+        dP = [None] * n
+        for i in range(n - 1, 0, -1):
+            u1, u2 = net.pa1[i - 1], net.pa2[i - 1]
+            g = d[i] if d[i] is not None else torch.zeros_like(outs[i])
+            if u2.relu:
+                g = ops.add_relu_mask(g, None, outs[i])
+            unit_grads[u2] = unit_wgrad(u2, ctx.s_saved[i - 1], g)
+            ds = unit_dgrad(u2, g, _hw(ctx.s_saved[i - 1]))
+            dP[i] = ds
+            dt = ops.add_relu_mask(ds, None, ctx.t_saved[i - 1]) if u1.relu else ds
+            unit_grads[u1] = unit_wgrad(u1, outs[i - 1], dt)
+            d[i - 1] = unit_dgrad(u1, dt, _hw(outs[i - 1]), d[i - 1], ADD_SAME)
+        dP[0] = d[0]
+        flat = []
+        for u in net.units():
+            flat += unit_grads.get(u, [None] * len(u.params()))
+        join_side_stream(dev)
+        return (None,) + tuple(_as_nchw(t) if t is not None else None for t in dP) + tuple(flat)

@@ -1,3 +1,4 @@
 from .fpn import FPN
+from .pafpn import PAFPN
 
-__all__ = ['FPN']
+__all__ = ['FPN', 'PAFPN']

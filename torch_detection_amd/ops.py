@@ -357,6 +357,33 @@ def bbox_iou_pairwise(a, b):
     return out
 
 
+def _f4(vals):
+    vals = [float(v) for v in vals]
+    if len(vals) != 4:
+        raise AssertionError("means / stds must have 4 entries")
+    return (ctypes.c_float * 4)(*vals)
+
+
+def bbox_normalize_(bbox, means, stds):
+    """In place: bbox <- (bbox - means) / stds (datasets/utils/bbox.py:118-140). bbox: CUDA float32 (A, 4)."""
+    _chk_boxes(bbox, "bbox")
+    _lib.check(_lib.load().tdn_bbox_normalize(_ptr(bbox), bbox.shape[0], _f4(means), _f4(stds), _lib.stream_ptr()),
+               "tdn_bbox_normalize")
+    return bbox
+
+
+def bbox_denormalize(bbox, means, stds):
+    """bbox * stds + means, means/stds tiled over the 4C columns (datasets/utils/bbox.py:143-166)."""
+    if bbox.dtype != torch.float32 or not bbox.is_cuda or bbox.dim() != 2 or not bbox.is_contiguous():
+        raise ValueError("bbox must be a contiguous CUDA float32 (A, 4C) tensor")
+    if bbox.shape[1] % 4:
+        raise AssertionError("bbox.shape[1] must be a multiple of 4")
+    out = torch.empty_like(bbox)
+    _lib.check(_lib.load().tdn_bbox_denormalize(_ptr(bbox), _ptr(out), bbox.shape[0], bbox.shape[1], _f4(means),
+                                                _f4(stds), _lib.stream_ptr()), "tdn_bbox_denormalize")
+    return out
+
+
 def nms(boxes, scores, iou_thr):
     _chk_boxes(boxes, "boxes")
     N = boxes.shape[0]
