@@ -268,6 +268,35 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
         for (int kk = 0; kk < KSUB; ++kk) mfma_substep(sA, sB, kk);
       } else if constexpr (MODE == 4) {   // ABLATION (timing only, wrong results): loads only, no LDS reads / MFMA
         stage_load(fill);
+      } else if constexpr (MODE == 7) {   // ABLATION: MFMA only (fragments never re-read: pure matrix-pipe rate)
+        bf16x8_t wf[FN], xf[FM];
+#pragma unroll
+        for (int i = 0; i < FN; ++i) wf[i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[0]);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) xf[j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[0]);
+        if (t == 0) {
+          for (int rep = 0; rep < T * KSUB; ++rep) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+              for (int j = 0; j < FM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      } else if constexpr (MODE == 8) {   // ABLATION: LDS fragment reads only (kept live), no MFMA, no loads
+#pragma unroll
+        for (int kk = 0; kk < KSUB; ++kk) {
+#pragma unroll
+          for (int i = 0; i < FN; ++i) {
+            bf16x8_t v = lds_read_b128(sB + i * 16 * ROWB + rd_off[kk]);
+            asm volatile("" ::"v"(v));
+          }
+#pragma unroll
+          for (int j = 0; j < FM; ++j) {
+            bf16x8_t v = lds_read_b128(sA + j * 16 * ROWB + rd_off[kk]);
+            asm volatile("" ::"v"(v));
+          }
+        }
       } else if constexpr (MODE == 6) {
         // software-pipelined fragments: sub-step 1's LDS reads are issued between sub-step 0's MFMAs (second
         // register set), so only ONE LDS latency per K-step is exposed; the interleave is pinned with
@@ -467,6 +496,8 @@ static const GemmCfg kCfgs[] = {
     {64, 128, 64, 2, 2, 2, 6},   // 62
     {128, 128, 64, 2, 2, 2, 6},  // 63
     {256, 128, 64, 4, 2, 3, 6},  // 64
+    {192, 256, 64, 2, 4, 2, 7},  // 65  ablation: MFMA only
+    {192, 256, 64, 2, 4, 2, 8},  // 66  ablation: LDS reads only
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -573,7 +604,9 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
     case 61: return launch_gemm<192, 256, 64, 2, 4, 2, 6>(p, maxM, stream);
     case 62: return launch_gemm<64, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
     case 63: return launch_gemm<128, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
-    default: return launch_gemm<256, 128, 64, 4, 2, 3, 6>(p, maxM, stream);
+    case 64: return launch_gemm<256, 128, 64, 4, 2, 3, 6>(p, maxM, stream);
+    case 65: return launch_gemm<192, 256, 64, 2, 4, 2, 7>(p, maxM, stream);
+    default: return launch_gemm<192, 256, 64, 2, 4, 2, 8>(p, maxM, stream);
   }
 }
 

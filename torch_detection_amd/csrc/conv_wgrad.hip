@@ -34,24 +34,40 @@ __device__ __forceinline__ int tr_swz(int row) {
   else return (row >> 3) & 1;
 }
 
-template <int BMW /*co*/, int BNW /*ci*/>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+template <int BMW /*co*/, int BNW /*ci*/, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BKW = 64;                       // pixels per stage
   constexpr int RBG = BMW * 2, RBX = BNW * 2;   // row bytes
   constexpr int G_BYTES = BKW * RBG, X_BYTES = BKW * RBX, STAGE = G_BYTES + X_BYTES;
   constexpr int RPIG = 1024 / RBG, RPIX = 1024 / RBX;   // rows per wave-instruction
-  constexpr int G_IT = BKW / (RPIG * 4) > 0 ? BKW / (RPIG * 4) : 1;
-  constexpr int X_IT = BKW / (RPIX * 4) > 0 ? BKW / (RPIX * 4) : 1;
-  constexpr bool G_PART = (RPIG * 4 > BKW), X_PART = (RPIX * 4 > BKW);  // fewer than 4 waves needed
-  constexpr int WTM = BMW / 2, WTN = BNW / 2, FM = WTM / 16, FN = WTN / 16;  // per-wave co / ci frags
+  constexpr int NW = WM * WN;
+  constexpr int G_IT = BKW / (RPIG * NW) > 0 ? BKW / (RPIG * NW) : 1;
+  constexpr int X_IT = BKW / (RPIX * NW) > 0 ? BKW / (RPIX * NW) : 1;
+  constexpr bool G_PART = (RPIG * NW > BKW), X_PART = (RPIX * NW > BKW);  // fewer than NW waves needed
+  constexpr int WTM = BMW / WM, WTN = BNW / WN, FM = WTM / 16, FN = WTN / 16;  // per-wave co / ci frags
   static_assert(FM >= 1 && FN >= 1, "tile too small");
+  // the per-lane swizzle constants assume the row offset between a lane's loads keeps row bits 0..3
+  static_assert((RPIG * NW) % 16 == 0 && (RPIX * NW) % 16 == 0, "loader round must be a multiple of 16 rows");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  const int tile = blockIdx.x;
+  // XCD-aware work map: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch; speed only).  XCD x owns
+  // the pixel splits s = x (mod 8) and walks all tiles of one split before the next, so the ~ntiles workgroups
+  // that stream the same g / x pixel range run together on ONE L2 instead of being dealt over all eight.
+  const int ntiles = p.tiles_co * p.tiles_k;
+  int split, tile;
+  if (p.splitk >= 8) {
+    const int xj = blockIdx.x >> 3;
+    split = (blockIdx.x & 7) + 8 * (xj / ntiles);
+    tile = xj - (xj / ntiles) * ntiles;
+  } else {   // too few splits to feed 8 XCDs that way: plain order, tile fastest
+    split = blockIdx.x / ntiles;
+    tile = blockIdx.x - split * ntiles;
+  }
+  if (split >= p.splitk) return;
   const int tile_co = tile % p.tiles_co, tile_k = tile / p.tiles_co;
   const int co0 = tile_co * BMW;
   const int kt_per_tap = p.Ktap / BNW;
@@ -59,7 +75,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int ci0 = (tile_k - tap_i * kt_per_tap) * BNW;
   const int tp = p.taps[tap_i];
   const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64;
-  const int split = blockIdx.y;
   const int m_begin = split * p.Mchunk;
   const int m_end = min(p.M, m_begin + p.Mchunk);
 
@@ -67,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int CPRG = RBG / 16, CPRX = RBX / 16;  // 16B chunks per row
   const int g_lrow = lane / CPRG, g_pc = lane % CPRG;
   const int x_lrow = lane / CPRX, x_pc = lane % CPRX;
-  const int g_row0 = wave * RPIG + g_lrow;   // + it*RPIG*4
+  const int g_row0 = wave * RPIG + g_lrow;   // + it*RPIG*NW
   const int x_row0 = wave * RPIX + x_lrow;
   const int g_src_el = ((((g_pc >> 1) ^ tr_swz<RBG>(g_row0)) << 1) | (g_pc & 1)) * 8;
   const int x_src_el = ((((x_pc >> 1) ^ tr_swz<RBX>(x_row0)) << 1) | (x_pc & 1)) * 8;
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int it = 0; it < X_IT; ++it) {
-    const int m = m_begin + it * (RPIX * 4) + x_row0;
+    const int m = m_begin + it * (RPIX * NW) + x_row0;
     const int img = m / HoWo;
     const int rem = m - img * HoWo;
     ximg[it] = img;
@@ -92,22 +107,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     if (!G_PART || g_row0 < BKW) {
 #pragma unroll
       for (int it = 0; it < G_IT; ++it) {
-        const int r = it * (RPIG * 4) + g_row0;
+        const int r = it * (RPIG * NW) + g_row0;
         const int m = mt + r;
         const bf16_t* src = (m < m_end) ? p.g + ((int64_t)m * p.Cout + co0 + g_src_el) : zero + (g_src_el & 127);
-        glds16(src, sG + (it * (RPIG * 4) + wave * RPIG) * RBG);
+        glds16(src, sG + (it * (RPIG * NW) + wave * RPIG) * RBG);
       }
     }
     if (!X_PART || x_row0 < BKW) {
 #pragma unroll
       for (int it = 0; it < X_IT; ++it) {
-        const int r = it * (RPIX * 4) + x_row0;
+        const int r = it * (RPIX * NW) + x_row0;
         const int m = mt + r;
         const int h = xa[it] * p.sa + dh, w = xb[it] * p.sa + dw;
         const bool ok = (m < m_end) && ((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win);
         const bf16_t* src = ok ? p.x + (((int64_t)(ximg[it] * p.Hin + h) * p.Win + w) * p.Cpix + ci0 + x_src_el)
                                : zero + (x_src_el & 127);
-        glds16(src, sX + (it * (RPIX * 4) + wave * RPIX) * RBX);
+        glds16(src, sX + (it * (RPIX * NW) + wave * RPIX) * RBX);
         // advance to the next stage's pixel
         xb[it] += BKW;
         while (xb[it] >= p.Wo) { xb[it] -= p.Wo; xa[it] += 1; }
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   };
 
   // ---- fragment reader constants (ds_read_b64_tr_b16) ----
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   const int rrow = 8 * grp + q;                 // + kk*32 + 4*half
   const int fG = tr_swz<RBG>(rrow), fX = tr_swz<RBX>(rrow);
@@ -299,12 +314,14 @@ struct WgradPlan { int bmw, bnw, tiles_co, tiles_k, splitk, mchunk, M, Ktot; };
 
 static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps) {
   WgradPlan w;
-  w.bmw = (Cout % 128 == 0) ? 128 : 64;
-  w.bnw = (Ktap % 64 == 0) ? 64 : 32;   // 128x64 measured ~4% faster over the whole step than 128x128
+  // measured (scripts/wgrad_bench.py): 64-wide ci tiles beat 128; 256-wide co tiles (8 waves) win when Cout allows,
+  // except for the small-M 3x3 layers where the extra workgroups of the 128-wide tile matter more
+  w.bmw = (Cout % 256 == 0 && !(ntaps > 1 && M < 20000)) ? 256 : ((Cout % 128 == 0) ? 128 : 64);
+  w.bnw = (Ktap % 64 == 0) ? 64 : 32;
   if (const char* env = getenv("TDN_WGRAD_TILE")) {   // tuning override: "BMWxBNW" with 64/128 entries
     int a = 0, b = 0;
-    if (sscanf(env, "%dx%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 64 || b == 128) && Cout % a == 0 &&
-        Ktap % b == 0) {
+    if (sscanf(env, "%dx%d", &a, &b) == 2 && (a == 64 || a == 128 || a == 256) && (b == 64 || b == 128) &&
+        Cout % a == 0 && Ktap % b == 0) {
       w.bmw = a;
       w.bnw = b;
     }
@@ -325,6 +342,8 @@ static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps) {
   if (splitk > max_split) splitk = max_split;
   if (splitk > 256) splitk = 256;
   if (splitk < 1) splitk = 1;
+  // splits are dealt round-robin to the 8 XCD labels (kernel's work map): keep the per-XCD load even
+  if (splitk >= 8) splitk = (splitk + 4) / 8 * 8;
   int mchunk = ceil_div(ceil_div(M, splitk), 64) * 64;
   splitk = ceil_div(M, mchunk);
   w.splitk = splitk;
@@ -336,11 +355,19 @@ static int64_t wgrad_ws_bytes(const WgradPlan& w, int Cout) {
   return ((int64_t)w.splitk * Cout * w.Ktot + (int64_t)w.splitk * Cout) * 4 + 256;
 }
 
-template <int BMW, int BNW>
+template <int BMW, int BNW, int WM = 2, int WN = 2>
 static int launch_wgrad(const WgradParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)64 * (BMW + BNW) * 2;
-  dim3 grid(p.tiles_co * p.tiles_k, p.splitk, 1), block(256, 1, 1);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW>), grid, block, lds, stream, p);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, WM, WN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int slots = p.splitk >= 8 ? 8 * ((p.splitk + 7) / 8) : p.splitk;   // see the kernel's work map
+  dim3 grid(slots * p.tiles_co * p.tiles_k, 1, 1), block(WM * WN * 64, 1, 1);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WM, WN>), grid, block, lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -356,7 +383,9 @@ static int run_wgrad(WgradParams& p, const WgradPlan& w, const void* w_fwd, cons
   p.M = w.M; p.Mchunk = w.mchunk; p.splitk = w.splitk; p.Ktot = w.Ktot;
   p.tiles_co = w.tiles_co; p.tiles_k = w.tiles_k;
   int rc;
-  if (w.bmw == 128 && w.bnw == 128) rc = launch_wgrad<128, 128>(p, stream);
+  if (w.bmw == 256 && w.bnw == 128) rc = launch_wgrad<256, 128, 4, 2>(p, stream);
+  else if (w.bmw == 256 && w.bnw == 64) rc = launch_wgrad<256, 64, 4, 2>(p, stream);
+  else if (w.bmw == 128 && w.bnw == 128) rc = launch_wgrad<128, 128>(p, stream);
   else if (w.bmw == 128 && w.bnw == 64) rc = launch_wgrad<128, 64>(p, stream);
   else if (w.bmw == 64 && w.bnw == 128) rc = launch_wgrad<64, 128>(p, stream);
   else if (w.bmw == 64 && w.bnw == 64) rc = launch_wgrad<64, 64>(p, stream);
