@@ -34,7 +34,7 @@ struct GemmParams {
   int sa, so;
   int addend_mode, addend_h, addend_w, relu, out_f32;
   int tiles_n, nwg_pad;
-  int ncls;
+  int ncls, krot;
   GemmClass cls[4];
 };
 
@@ -129,7 +129,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
   // a pixel or a row), so within ~ntaps K-steps the workgroups of an XCD re-read a working set of
   // (pixels + halo) x 128 B instead of cycling through the whole (pixels x Cin) slab — the latter overflows the
   // 4 MB L2 for 256-channel 3x3 layers and drops the LDS-DMA stream to Infinity-Cache speed (~10 TB/s measured).
-  int ld_tap = 0, ld_kc = 0;   // (tap, channel chunk) of the next K-step to be issued: stage_load runs in t order
+  // Every workgroup starts its K loop at a different channel chunk (the sum over K is order-independent): tiles run
+  // in near lock-step, and with all of them on chunk c at once every row they request (pixel stride Cin*2 B,
+  // weight-row stride K*2 B — multiples of 512 B) lands on the same few L2 channels.  Opt-in: TDN_KROT=1.
+  int ld_tap = 0, ld_issued = 0;
+  int ld_kc = p.krot ? (tile_m + tile_n) % kchunks : 0;   // (tap, channel chunk) of the next K-step to be issued
   // tap table in a VGPR (lane i = tap i) and fetched with v_readlane: a scalar load per K-step would put an
   // s_waitcnt lgkmcnt(0) — which also drains the LDS fragment reads — on the critical path
   const int tapv = (lane < c.ntaps) ? c.taps[lane < 9 ? lane : 0] : 0;
@@ -139,7 +143,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
   auto stage_load = [&](int s) {
     char* sA = smem + s * STAGE + wave * (RPI * ROWB);
     char* sB = sA + A_BYTES;
-    if (ld_kc < kchunks) {
+    if (ld_issued < T) {
+      ++ld_issued;
       const int tp = __builtin_amdgcn_readlane(tapv, ld_tap);
       const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
       const int64_t uoff_a = ((int64_t)(dh * p.Win + dw) * p.Cpix + ld_kc * BK) * 2;   // wave-uniform
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
       }
 #pragma unroll
       for (int it = 0; it < B_IT; ++it) glds16(wt_u + b_off[it], sB + it * (RPI * NW * ROWB));
-      if (++ld_tap == c.ntaps) { ld_tap = 0; ++ld_kc; }   // taps innermost (see K-order note above)
+      if (++ld_tap == c.ntaps) { ld_tap = 0; ld_kc = (ld_kc + 1 == kchunks) ? 0 : ld_kc + 1; }   // taps innermost
     } else {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) glds16(zero_src, sA + it * (RPI * NW * ROWB));
@@ -498,6 +503,13 @@ static const GemmCfg kCfgs[] = {
     {256, 128, 64, 4, 2, 3, 6},  // 64
     {192, 256, 64, 2, 4, 2, 7},  // 65  ablation: MFMA only
     {192, 256, 64, 2, 4, 2, 8},  // 66  ablation: LDS reads only
+    {64, 128, 64, 2, 4, 2, 0},   // 67  8 waves, wave tile 32x32, 48 KB
+    {128, 64, 64, 2, 4, 2, 0},   // 68  8 waves, wave tile 64x16
+    {64, 128, 64, 2, 4, 3, 0},   // 69  8 waves, 3 stages 72 KB
+    {128, 128, 64, 4, 4, 2, 0},  // 70  16 waves, wave tile 32x32, 64 KB
+    {64, 64, 64, 2, 4, 2, 0},    // 71  8 waves, wave tile 32x16
+    {64, 128, 64, 2, 4, 2, 4},   // 72  loads only, 8 waves
+    {128, 128, 64, 4, 4, 2, 4},  // 73  loads only, 16 waves
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -521,6 +533,10 @@ static int choose_cfg(int maxM, int ngemm) {
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0>
 static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   p.tiles_n = p.Cout / BN;
+  {
+    const char* kr = getenv("TDN_KROT");
+    p.krot = (kr && kr[0] == '1') ? 1 : 0;   // measured: no gain (profiles/), off keeps results tile-independent
+  }
   const int ntiles = ceil_div(maxM, BM) * p.tiles_n;
   p.nwg_pad = (ntiles + 7) & ~7;
   constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 2;
@@ -606,7 +622,14 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
     case 63: return launch_gemm<128, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
     case 64: return launch_gemm<256, 128, 64, 4, 2, 3, 6>(p, maxM, stream);
     case 65: return launch_gemm<192, 256, 64, 2, 4, 2, 7>(p, maxM, stream);
-    default: return launch_gemm<192, 256, 64, 2, 4, 2, 8>(p, maxM, stream);
+    case 66: return launch_gemm<192, 256, 64, 2, 4, 2, 8>(p, maxM, stream);
+    case 67: return launch_gemm<64, 128, 64, 2, 4, 2, 0>(p, maxM, stream);
+    case 68: return launch_gemm<128, 64, 64, 2, 4, 2, 0>(p, maxM, stream);
+    case 69: return launch_gemm<64, 128, 64, 2, 4, 3, 0>(p, maxM, stream);
+    case 70: return launch_gemm<128, 128, 64, 4, 4, 2, 0>(p, maxM, stream);
+    case 71: return launch_gemm<64, 64, 64, 2, 4, 2, 0>(p, maxM, stream);
+    case 72: return launch_gemm<64, 128, 64, 2, 4, 2, 4>(p, maxM, stream);
+    default: return launch_gemm<128, 128, 64, 4, 4, 2, 4>(p, maxM, stream);
   }
 }
 
