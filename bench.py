@@ -28,6 +28,10 @@ FWD_GFLOP = {50: 296.96, 101: 456.06}     # per image, SURVEY §8(d)
 FWDBWD_GFLOP = {50: 885.8, 101: 1363.1}   # 3*fwd - dgrad(conv1)
 MFMA_PEAK_TFLOPS = 2500.0          # bf16 dense, MI355X_MICROARCH.md
 DOM = dict(Cin=256, Cout=256, k=3, stride=1, H=200, W=336)   # neck.fpn_convs.0: 79.27 GFLOP / image
+# HBM bytes of ONE launch of that kernel at batch 2 from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes,
+# FETCH_SIZE doubled per MI355X_MICROARCH.md): filled in from profiles/ (None until measured)
+DOM_TRAFFIC_BYTES = 1.743e8  # 2*FETCH_SIZE(51488 KiB) + WRITE_SIZE(67200 KiB); algorithmic 1.388e8
+DOM_TRAFFIC_SOURCE = "profiles/r01_pmc_dominant_kernel.txt"
 
 
 def build_models(depth, device, seed=0):
@@ -50,31 +54,44 @@ def build_models(depth, device, seed=0):
 
 
 class KernelTimer(object):
-    """HIP-event timing of ONE kernel launch shape (the dominant conv) on the stream it is launched on."""
+    """HIP-event timing of the dominant kernel instantiation (conv_gemm_kernel<192,256,64,2,4,2,6,1>: the 3x3
+    256->256 conv GEMM at M = N*200*336 — neck.fpn_convs.0 forward and its dgrad, 2 launches per step) on the stream
+    it is launched on."""
 
     def __init__(self, ops, match):
         self.ops, self.match, self.pairs = ops, match, []
-        self._orig = ops.conv2d_fwd
+        self._fwd, self._dgrad = ops.conv2d_fwd, ops.conv2d_dgrad
+
+    def _timed(self, fn, nimg, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = fn(*a, **kw)
+        e1.record()
+        self.pairs.append((e0, e1, nimg))
+        return y
 
     def __enter__(self):
-        orig, match, pairs = self._orig, self.match, self.pairs
+        m = self.match
 
-        def timed(x, w_fwd, k, stride, pad, *a, **kw):
-            hit = (tuple(x.shape[1:]) == (match["H"], match["W"], match["Cin"]) and w_fwd.shape[0] == match["Cout"]
-                   and k == match["k"] and stride == match["stride"])
+        def fwd(x, w_fwd, k, stride, pad, *a, **kw):
+            hit = (tuple(x.shape[1:]) == (m["H"], m["W"], m["Cin"]) and w_fwd.shape[0] == m["Cout"] and k == m["k"]
+                   and stride == m["stride"])
             if not hit:
-                return orig(x, w_fwd, k, stride, pad, *a, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            y = orig(x, w_fwd, k, stride, pad, *a, **kw)
-            e1.record()
-            pairs.append((e0, e1, x.shape[0]))
-            return y
-        self.ops.conv2d_fwd = timed
+                return self._fwd(x, w_fwd, k, stride, pad, *a, **kw)
+            return self._timed(self._fwd, x.shape[0], x, w_fwd, k, stride, pad, *a, **kw)
+
+        def dgrad(g, w_dgrad, in_hw, k, stride, pad, *a, **kw):
+            hit = (tuple(g.shape[1:]) == (m["H"], m["W"], m["Cout"]) and w_dgrad.shape[0] == m["Cin"] and k == m["k"]
+                   and stride == m["stride"] and tuple(in_hw) == (m["H"], m["W"]))
+            if not hit:
+                return self._dgrad(g, w_dgrad, in_hw, k, stride, pad, *a, **kw)
+            return self._timed(self._dgrad, g.shape[0], g, w_dgrad, in_hw, k, stride, pad, *a, **kw)
+
+        self.ops.conv2d_fwd, self.ops.conv2d_dgrad = fwd, dgrad
         return self
 
     def __exit__(self, *exc):
-        self.ops.conv2d_fwd = self._orig
+        self.ops.conv2d_fwd, self.ops.conv2d_dgrad = self._fwd, self._dgrad
 
     def summary(self):
         if not self.pairs:
@@ -265,9 +282,11 @@ def main():
             flop = 2.0 * nimg * DOM["H"] * DOM["W"] * DOM["Cout"] * DOM["Cin"] * DOM["k"] ** 2
             ach = flop / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": "conv_gemm_kernel<128,128,64> @ neck.fpn_convs.0 fwd (M=%d,N=256,K=2304)" %
-                              (nimg * DOM["H"] * DOM["W"]),
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": DOM_TRAFFIC_BYTES if nimg == 2 else None, "traffic_source": DOM_TRAFFIC_SOURCE,
+                    "kernel": "conv_gemm_kernel<192,256,64,2,4,2,6,1> = 3x3 256->256 conv GEMM, M=%d N=256 K=2304 "
+                              "(neck.fpn_convs.0 forward + its dgrad, 2 launches/step), %.1f GFLOP per launch" %
+                              (nimg * DOM["H"] * DOM["W"], flop / 1e9),
                     "avg_ms": round(ms, 4), "launches_timed": cnt, "timed_in": timed_in}
         line = {
             "metric": "images/sec ResNet-50-FPN fwd+bwd 1333x800" if args.depth == 50 else
