@@ -202,6 +202,11 @@ int tdn_bbox_denormalize(const float* bbox, float* out, int64_t rows, int cols, 
 int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad,
                     int32_t* out16);
 
+/* Diagnostics only: registers a device buffer of `bytes` bytes into which the tracing builds of the conv GEMM
+ * kernel (selected with the TDN_GEMM_CFG environment variable, scripts/trace_gemm.py) write 32 64-bit shader-clock
+ * stamps per workgroup.  buf = NULL disables tracing.  No reference counterpart. */
+int tdn_debug_trace(void* buf, long long bytes);
+
 #ifdef __cplusplus
 }
 #endif

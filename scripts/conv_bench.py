@@ -46,8 +46,8 @@ def timeit(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=2)
-    ap.add_argument("--cfgs", default="0,1,2,3,4,7,8,11")
-    ap.add_argument("--cfgs64", default="5,6,9,10")
+    ap.add_argument("--cfgs", default="0,1,2,3,4,5,7")
+    ap.add_argument("--cfgs64", default="0,6")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="fwd", choices=["fwd", "dgrad"])
     ap.add_argument("--filter", default="")

@@ -35,8 +35,19 @@ struct GemmParams {
   int addend_mode, addend_h, addend_w, relu, out_f32;
   int tiles_n, nwg_pad;
   int ncls, krot;
+  unsigned long long* trace;   // TAG 2 instantiations only: 32 timestamps per workgroup (scripts/trace_gemm.py)
   GemmClass cls[4];
 };
+
+// s_memtime stamp of (workgroup, slot): wave 0 only, written at the end of the kernel from SGPR-held values would
+// perturb less, but a direct store is good enough for a +-50 cycle picture of the pipeline
+#define TDN_TRACE(slot)                                                                                       \
+  do {                                                                                                        \
+    if constexpr (TAG == 2) {                                                                                 \
+      if (p.trace && tid == 0)                                                                                \
+        p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + (slot)] = __builtin_readcyclecounter(); \
+    }                                                                                                         \
+  } while (0)
 
 
 template <int BK>
@@ -55,14 +66,21 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // <BM x BN> output tile (pixels x channels), BK-deep K-steps, WM x WN waves (wave tile BM/WM x BN/WN),
 // NSTAGE-deep LDS ring filled by LDS-DMA: while K-step t is multiplied, the loads of steps t+1 .. t+NSTAGE-2 stay
 // in flight (counted vmcnt, one s_barrier per K-step).
-// MODE 0: LDS-DMA issued right after the barrier;  MODE 1: LDS-DMA issued between the two MFMA sub-steps.
+// MODE 0: fragments read per 32-deep sub-step;  MODE 6: sub-step 1's fragment reads issued under sub-step 0's MFMAs.
+// (Measured and dropped: mid-step DMA issue, reads-first, phase-staggered wave groups, BK = 32 rings.)
 // (Register staging — global_load_dwordx4 -> VGPR -> ds_write_b128 — measured the same as LDS-DMA and was dropped.)
 // TAG only changes the kernel's symbol name: TAG 1 is the instantiation reserved for the heaviest shape of the net
 // (3x3, 256 -> 256 at M >= 100000: neck.fpn_convs.0 forward and its dgrad) so that rocprofv3 --stats reports that
 // launch on a line of its own, directly comparable with bench.py's HIP-event timing of the same launch.
-template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0, int TAG = 0>
-__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// KG > 1: in-workgroup split-K.  The workgroup holds KG groups of WM x WN waves; group g owns its own LDS ring and
+// multiplies K-steps g, g+KG, g+2KG, ... of the SAME output tile; the KG partial accumulators are summed through LDS
+// in a fixed order and the epilogue is shared out over the groups.  Reason (scripts/trace_gemm.py): one
+// wave sustains only ~4 B/clk of LDS-DMA however many loads it keeps in flight, a CU needs ~16 loading waves to reach
+// its ~40 B/clk L2->LDS rate, and the small-M layers (layer3/4, FPN top levels) have too few output tiles to put
+// four 4-wave workgroups on every CU — so the extra waves are recruited along K instead.
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0, int TAG = 0, int KG = 1>
+__global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
   constexpr int NW = WM * WN;
   constexpr int ROWB = BK * 2;
   constexpr int CH = BK / 8;
@@ -76,12 +94,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
   static_assert(A_IT >= 1 && B_IT >= 1 && FM >= 1 && FN >= 1, "tile too small for this wave layout");
   static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "loader does not tile evenly");
   static_assert(NSTAGE >= 2 && LOADS * (NSTAGE - 2) < 64, "vmcnt immediate out of range");
+  static_assert(KG == 1 || (MODE == 0 || MODE == 6), "split-K groups: production schedules only");
+  static_assert(KG == 1 || BM * BN * 4 <= NSTAGE * STAGE, "partial sums must fit the group's LDS ring");
+  constexpr bool EARLY_EPI = FN * FM <= 8;   // small tiles: fetch scale/shift before the K loop (registers to spare)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KG == 1 ? 0 : wave_all / NW;     // split-K group of this wave
+  const int wave = KG == 1 ? wave_all : wave_all % NW;   // wave index inside its group
+  char* smem = smem_all + grp * (NSTAGE * STAGE);
   const GemmClass& c = p.cls[blockIdx.y];
+  int taps_s[9];   // the class's tap table in scalar registers: nine loads in flight at once, one wait
+#pragma unroll
+  for (int i = 0; i < 9; ++i) taps_s[i] = c.taps[i];
+  const int ntaps = c.ntaps;
 
+  TDN_TRACE(0);
   const int bid = blockIdx.x;
   const int tile = (bid & 7) * (p.nwg_pad >> 3) + (bid >> 3);
   const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
@@ -112,10 +141,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
       const int b = rem - a * c.Wa;
       const int h0 = a * p.sa, w0 = b * p.sa;
       a_base[it] = (const char*)p.in + ((int64_t)((img * p.Hin + h0) * p.Win + w0) * p.Cpix + src_chunk_el) * 2;
-      for (int ti = 0; ti < c.ntaps; ++ti) {
-        const int tp = c.taps[ti];
+#pragma unroll
+      for (int ti = 0; ti < 9; ++ti) {
+        const int tp = taps_s[ti];
         const int h = h0 + (tp & 0xff) - 64, w = w0 + ((tp >> 8) & 0xff) - 64;
-        if (((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win)) a_valid[it] |= 1u << ti;
+        if (ti < ntaps && ((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win)) a_valid[it] |= 1u << ti;
       }
     }
   }
@@ -127,7 +157,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
   }
 
   const int kchunks = p.Ktap / BK;
-  const int T = c.ntaps * kchunks;
+  const int T = ntaps * kchunks;
+  const int Tg = KG == 1 ? T : (T + KG - 1) / KG;   // K-steps per group (the same for every group: shared barriers)
   // K order: channel chunk outermost, taps innermost.  All taps of a chunk touch the same input lines (shifted by
   // a pixel or a row), so within ~ntaps K-steps the workgroups of an XCD re-read a working set of
   // (pixels + halo) x 128 B instead of cycling through the whole (pixels x Cin) slab — the latter overflows the
@@ -135,11 +166,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
   // Every workgroup starts its K loop at a different channel chunk (the sum over K is order-independent): tiles run
   // in near lock-step, and with all of them on chunk c at once every row they request (pixel stride Cin*2 B,
   // weight-row stride K*2 B — multiples of 512 B) lands on the same few L2 channels.  Opt-in: TDN_KROT=1.
-  int ld_tap = 0, ld_issued = 0;
+  int ld_tap = 0, ld_issued = grp;   // ld_issued: global index of the next K-step this group issues
   int ld_kc = p.krot ? (tile_m + tile_n) % kchunks : 0;   // (tap, channel chunk) of the next K-step to be issued
-  // tap table in a VGPR (lane i = tap i) and fetched with v_readlane: a scalar load per K-step would put an
-  // s_waitcnt lgkmcnt(0) — which also drains the LDS fragment reads — on the critical path
-  const int tapv = (lane < c.ntaps) ? c.taps[lane < 9 ? lane : 0] : 0;
+  auto advance_k = [&]() {   // taps innermost
+    if (++ld_tap == ntaps) { ld_tap = 0; ld_kc = (ld_kc + 1 == kchunks) ? 0 : ld_kc + 1; }
+  };
+  if constexpr (KG > 1) {
+    for (int i = 0; i < grp; ++i) advance_k();
+  }
+  // tap table in a VGPR (lane i = tap i) and fetched with v_readlane: the K loop indexes it dynamically, and a
+  // scalar load per K-step would put an s_waitcnt lgkmcnt(0) — which also drains the LDS fragment reads — on the
+  // critical path
+  int tapv = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) tapv = (lane == i) ? taps_s[i] : tapv;
 
   // issue the LDS-DMA of the next K-step into ring slot s (past the end: dummy loads of the zero page keep the
   // vmcnt bookkeeping uniform)
@@ -147,7 +187,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
     char* sA = smem + s * STAGE + wave * (RPI * ROWB);
     char* sB = sA + A_BYTES;
     if (ld_issued < T) {
-      ++ld_issued;
+      ld_issued += KG;
       const int tp = __builtin_amdgcn_readlane(tapv, ld_tap);
       const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
       const int64_t uoff_a = ((int64_t)(dh * p.Win + dw) * p.Cpix + ld_kc * BK) * 2;   // wave-uniform
@@ -160,7 +200,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
       }
 #pragma unroll
       for (int it = 0; it < B_IT; ++it) glds16(wt_u + b_off[it], sB + it * (RPI * NW * ROWB));
-      if (++ld_tap == c.ntaps) { ld_tap = 0; ld_kc = (ld_kc + 1 == kchunks) ? 0 : ld_kc + 1; }   // taps innermost
+#pragma unroll
+      for (int i = 0; i < KG; ++i) advance_k();
     } else {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) glds16(zero_src, sA + it * (RPI * NW * ROWB));
@@ -196,75 +237,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
   };
 
-  if constexpr (MODE == 5) {
-    // Phase-staggered schedule for 8 waves = two groups of four (waves w and w+4 share a SIMD).  Every K-step is
-    // two phases separated by barriers; in each phase one group multiplies from REGISTER fragments while the other
-    // group reads its fragments of the current stage from LDS, so on every SIMD the matrix pipe and the LDS pipe
-    // always have a customer:
-    //     even phase 2u : all waves issue the LDS-DMA of stage u+1;  G0 reads stage u;   G1 multiplies stage u-1
-    //     odd  phase 2u+1:                                          G0 multiplies u;    G1 reads stage u
-    // Stage u+1 (slot (u+1)&1) was last read in odd phase 2u-1 and is needed again in even phase 2u+2: its DMA has
-    // two phases to land (every wave waits vmcnt(0) at the end of the odd phase, before the barrier).
-    static_assert(NSTAGE == 2 && WM == 2 && WN == 4, "staggered schedule: 2 LDS slots, 2x4 waves");
-    const bool g0 = wm == 0;
-    // one 32-deep sub-step per phase pair keeps the register fragments at (FM+FN) x 4 VGPRs
-    bf16x8_t wf[FN], xf[FM];
-    auto read_frags = [&](int slot, int kk) {
-      const char* sA = smem + slot * STAGE + (wm * WTM) * ROWB;
-      const char* sB = smem + slot * STAGE + A_BYTES + (wn * WTN) * ROWB;
+  // epilogue constants; with KG groups, fragment (i, j) is finished by group (i*FM + j) % KG
+  const int ch_base = n0 + wn * WTN + fq * 4;
+  f32x4_t sc[FN], sh[FN];
+  auto load_affine = [&]() {
 #pragma unroll
-      for (int i = 0; i < FN; ++i) wf[i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[kk]);
-#pragma unroll
-      for (int j = 0; j < FM; ++j) xf[j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[kk]);
-    };
-    auto multiply = [&]() {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    if (T > 0) {
-      stage_load(0);
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      bool pending = false;   // G1 holds fragments that still have to be multiplied
-      for (int u = 0; u < T; ++u) {
-#pragma unroll
-        for (int kk = 0; kk < KSUB; ++kk) {
-          // ---- even phase: G0 reads sub-step (u, kk); G1 multiplies the previous sub-step ----
-          if (kk == 0 && u + 1 < T) stage_load((u + 1) & 1);
-          if (g0) {
-            read_frags(u & 1, kk);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          } else if (pending) {
-            multiply();
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_barrier" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          // ---- odd phase: G0 multiplies (u, kk); G1 reads it ----
-          if (g0) {
-            multiply();
-          } else {
-            read_frags(u & 1, kk);
-            pending = true;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (kk == KSUB - 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (!g0) multiply();
+    for (int i = 0; i < FN; ++i) {
+      sc[i] = p.scale ? *(const f32x4_t*)(p.scale + ch_base + i * 16) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+      sh[i] = p.shift ? *(const f32x4_t*)(p.shift + ch_base + i * 16) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
-  } else if (T > 0) {
+  };
+  if constexpr (EARLY_EPI) load_affine();   // older than every LDS-DMA: the counted vmcnt waits retire them first
+
+  if (T > 0) {
+    TDN_TRACE(1);
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) stage_load(s);
+    TDN_TRACE(2);
     int slot = 0, fill = NSTAGE - 1;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < Tg; ++t) {
       wait_vm_and_barrier<LOADS * (NSTAGE - 2)>();   // K-step t has landed for every wave; slot (t-1) is free
+      if (t < 24) TDN_TRACE(3 + t);
       const char* sA = smem + slot * STAGE + (wm * WTM) * ROWB;
       const char* sB = smem + slot * STAGE + A_BYTES + (wn * WTN) * ROWB;
       if constexpr (MODE == 0) {
@@ -335,46 +328,43 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x8, 2 * FN * FM - (FN + FM), 0);
-      } else if constexpr (MODE == 2) {
-        // all fragment reads of the K-step first (one exposed LDS latency per step instead of one per
-        // read group), the LDS-DMA of the next step behind them, then the MFMAs
-        bf16x8_t wf[KSUB][FN], xf[KSUB][FM];
-#pragma unroll
-        for (int kk = 0; kk < KSUB; ++kk) {
-#pragma unroll
-          for (int i = 0; i < FN; ++i) wf[kk][i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[kk]);
-#pragma unroll
-          for (int j = 0; j < FM; ++j) xf[kk][j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[kk]);
-        }
-        stage_load(fill);
-#pragma unroll
-        for (int kk = 0; kk < KSUB; ++kk)
-#pragma unroll
-          for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
       } else {
-        mfma_substep(sA, sB, 0);
-        stage_load(fill);
-#pragma unroll
-        for (int kk = 1; kk < KSUB; ++kk) mfma_substep(sA, sB, kk);
+        static_assert(MODE == 0, "unknown MODE");
       }
       slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
       fill = (fill + 1 == NSTAGE) ? 0 : fill + 1;
     }
     // drain the dummy tail loads before the LDS ring / registers are reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TDN_TRACE(27);
   }
 
-  // ---- epilogue: lane owns channels ch..ch+3 of pixel m for each (i, j) fragment ----
-  const int ch_base = n0 + wn * WTN + fq * 4;
-  f32x4_t sc[FN], sh[FN];
+  // ---- split-K groups: exchange the partial accumulators through LDS (the rings are idle now) ----
+  // layout: [group][wave][fragment][lane] x 16 B, conflict-free 16-byte accesses; summed in group order 0..KG-1 by
+  // whichever group owns the fragment, so the result does not depend on the ownership map
+  if constexpr (KG > 1) {
+    __builtin_amdgcn_s_barrier();   // every wave is done reading the rings
+    char* mine = smem_all + (((grp * NW + wave) * (FN * FM)) << 10) + lane * 16;
 #pragma unroll
-  for (int i = 0; i < FN; ++i) {
-    sc[i] = p.scale ? *(const f32x4_t*)(p.scale + ch_base + i * 16) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
-    sh[i] = p.shift ? *(const f32x4_t*)(p.shift + ch_base + i * 16) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) *(f32x4_t*)(mine + ((i * FM + j) << 10)) = acc[i][j];
+    __syncthreads();
   }
+  auto fragment = [&](int i, int j) -> f32x4_t {
+    if constexpr (KG == 1) {
+      return acc[i][j];
+    } else {
+      const char* src = smem_all + (((wave * (FN * FM)) + i * FM + j) << 10) + lane * 16;
+      f32x4_t v = *(const f32x4_t*)src;
+#pragma unroll
+      for (int g = 1; g < KG; ++g) v += *(const f32x4_t*)(src + ((g * NW * (FN * FM)) << 10));
+      return v;
+    }
+  };
+
+  // ---- epilogue: lane owns channels ch..ch+3 of pixel m for each (i, j) fragment ----
+  if constexpr (!EARLY_EPI) load_affine();
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
     const int m = m0 + wm * WTM + j * 16 + fr;
@@ -392,8 +382,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
       apix = ((int64_t)img * p.addend_h + 2 * oh) * p.addend_w + 2 * ow;
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
+      if (KG > 1 && (i * FM + j) % KG != grp) continue;
       const int ch = ch_base + i * 16;
-      f32x4_t v = acc[i][j] * sc[i] + sh[i];
+      f32x4_t v = fragment(i, j) * sc[i] + sh[i];
       if (p.addend_mode != TDN_ADD_NONE) {
         const bf16_t* ap = p.addend + apix * p.Cout + ch;
         bf16x4_t r = *(const bf16x4_t*)ap;
@@ -429,6 +420,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
       }
     }
   }
+  if constexpr (TAG == 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TDN_TRACE(28);
+    if (p.trace && tid == 0) {
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 29] = ((unsigned long long)xcc << 32) | hwid;
+      p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 30] = (unsigned long long)T;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -436,87 +439,46 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmParam
 // ---------------------------------------------------------------------------------------------
 static inline int pack_tap(int dh, int dw, int widx) { return (dh + 64) | ((dw + 64) << 8) | (widx << 16); }
 
-// Tile configurations. LDS = NSTAGE * (BM + BN) * BK * 2 bytes.
-struct GemmCfg { int bm, bn, bk, wm, wn, nstage, mode; };
+// Tile configurations. LDS = NSTAGE * (BM + BN) * BK * 2 bytes.  MODE 0: LDS-DMA of the next K-step right after the
+// barrier, fragments read per sub-step; MODE 6: fragment reads software-pipelined under the MFMAs; MODE 3/4/7/8:
+// timing-only ablations (wrong results); tag 2: cycle-stamp tracing build (tdn_debug_trace, scripts/trace_gemm.py).
+struct GemmCfg { int bm, bn, bk, wm, wn, nstage, mode, tag, kg = 1; };
 static const GemmCfg kCfgs[] = {
-    {128, 128, 64, 2, 2, 2, 0},  // 0   64 KB, 256 thr
-    {128, 128, 64, 2, 2, 3, 0},  // 1   96 KB
-    {128, 128, 64, 2, 2, 4, 0},  // 2  128 KB
-    {256, 128, 64, 4, 2, 3, 0},  // 3  144 KB, 512 thr
-    {256, 128, 64, 4, 2, 2, 0},  // 4   96 KB, 512 thr
-    {128, 64, 64, 2, 2, 3, 0},   // 5   72 KB
-    {128, 64, 64, 2, 2, 4, 0},   // 6   96 KB
-    {64, 128, 64, 2, 2, 4, 0},   // 7   96 KB
-    {64, 128, 64, 2, 2, 3, 0},   // 8   72 KB
-    {64, 64, 64, 2, 2, 4, 0},    // 9   64 KB
-    {256, 64, 64, 4, 2, 3, 0},   // 10 120 KB, 512 thr
-    {128, 128, 64, 2, 4, 3, 0},  // 11  96 KB, 512 thr
-    {128, 128, 64, 2, 2, 2, 1},  // 12  mid-issue DMA
-    {128, 128, 64, 2, 2, 3, 1},  // 13
-    {256, 128, 64, 4, 2, 3, 1},  // 14
-    {256, 128, 64, 4, 2, 2, 1},  // 15
-    {64, 128, 64, 2, 2, 3, 1},   // 16
-    {64, 128, 64, 2, 2, 2, 0},   // 17
-    {128, 64, 64, 2, 2, 2, 0},   // 18
-    {64, 64, 64, 2, 2, 2, 0},    // 19
-    {64, 128, 32, 2, 2, 2, 0},   // 20  24 KB
-    {64, 128, 32, 2, 2, 3, 0},   // 21  36 KB
-    {64, 128, 32, 2, 2, 4, 0},   // 22  48 KB
-    {128, 128, 32, 2, 2, 2, 0},  // 23  32 KB
-    {128, 128, 32, 2, 2, 3, 0},  // 24  48 KB
-    {32, 128, 64, 1, 4, 2, 0},   // 25  40 KB
-    {64, 256, 64, 2, 2, 2, 0},   // 26  80 KB
-    {128, 256, 64, 2, 2, 2, 0},  // 27  96 KB
-    {64, 128, 64, 2, 2, 2, 2},   // 28  reads-first
-    {128, 128, 64, 2, 2, 2, 2},  // 29
-    {256, 128, 64, 4, 2, 3, 2},  // 30
-    {64, 64, 64, 2, 2, 2, 2},    // 31
-    {256, 256, 32, 2, 4, 4, 0},  // 32  128 KB, 512 thr, wave tile 128x64
-    {256, 256, 64, 2, 4, 2, 0},  // 33  128 KB
-    {192, 256, 64, 2, 4, 2, 0},  // 34  112 KB
-    {256, 256, 32, 2, 4, 4, 2},  // 35  reads-first
-    {256, 128, 32, 4, 2, 4, 0},  // 36   96 KB
-    {128, 256, 64, 2, 4, 2, 0},  // 37   96 KB, 512 thr
-    {192, 256, 64, 2, 4, 2, 3},  // 38  ablation: compute only
-    {192, 256, 64, 2, 4, 2, 4},  // 39  ablation: loads only
-    {192, 256, 64, 2, 4, 2, 2},  // 40  reads-first
-    {192, 256, 64, 2, 4, 2, 1},  // 41  mid-issue
-    {192, 128, 64, 2, 4, 2, 0},  // 42  80 KB, wave tile 96x32
-    {192, 128, 64, 2, 2, 2, 0},  // 43  80 KB, 256 thr, wave tile 96x64
-    {256, 256, 32, 2, 4, 4, 4},  // 44  loads only
-    {128, 256, 32, 2, 4, 6, 4},  // 45  loads only, 6 x 24 KB
-    {64, 128, 64, 2, 2, 2, 4},   // 46  loads only
-    {128, 256, 32, 2, 4, 6, 0},  // 47  144 KB, 6-deep ring
-    {128, 256, 32, 2, 4, 4, 0},  // 48   96 KB
-    {256, 128, 32, 4, 2, 5, 0},  // 49  120 KB
-    {256, 256, 64, 4, 4, 2, 0},  // 50  128 KB, 1024 thr, wave tile 64x64
-    {128, 256, 64, 2, 8, 2, 0},  // 51   96 KB, 1024 thr, wave tile 64x32
-    {256, 128, 64, 4, 4, 2, 0},  // 52   96 KB, 1024 thr, wave tile 64x32
-    {256, 256, 64, 4, 4, 2, 4},  // 53  loads only
-    {256, 256, 64, 4, 4, 2, 3},  // 54  compute only
-    {192, 256, 64, 2, 4, 2, 5},  // 55  phase-staggered wave groups
-    {256, 256, 64, 2, 4, 2, 5},  // 56
-    {128, 256, 64, 2, 4, 2, 5},  // 57
-    {128, 128, 64, 2, 4, 2, 5},  // 58
-    {256, 128, 64, 2, 4, 2, 5},  // 59
-    {64, 128, 64, 2, 4, 2, 5},   // 60  wave tile 32x32
-    {192, 256, 64, 2, 4, 2, 6},  // 61  pipelined fragments
-    {64, 128, 64, 2, 2, 2, 6},   // 62
-    {128, 128, 64, 2, 2, 2, 6},  // 63
-    {256, 128, 64, 4, 2, 3, 6},  // 64
-    {192, 256, 64, 2, 4, 2, 7},  // 65  ablation: MFMA only
-    {192, 256, 64, 2, 4, 2, 8},  // 66  ablation: LDS reads only
-    {64, 128, 64, 2, 4, 2, 0},   // 67  8 waves, wave tile 32x32, 48 KB
-    {128, 64, 64, 2, 4, 2, 0},   // 68  8 waves, wave tile 64x16
-    {64, 128, 64, 2, 4, 3, 0},   // 69  8 waves, 3 stages 72 KB
-    {128, 128, 64, 4, 4, 2, 0},  // 70  16 waves, wave tile 32x32, 64 KB
-    {64, 64, 64, 2, 4, 2, 0},    // 71  8 waves, wave tile 32x16
-    {64, 128, 64, 2, 4, 2, 4},   // 72  loads only, 8 waves
-    {128, 128, 64, 4, 4, 2, 4},  // 73  loads only, 16 waves
+    {64, 64, 64, 2, 2, 2, 0, 0},     // 0   32 KB, 256 thr: Cout = 64 layers, tiny grids
+    {64, 128, 64, 2, 2, 2, 6, 0},    // 1   48 KB, 256 thr: mid-size layers
+    {128, 128, 64, 2, 2, 2, 6, 0},   // 2   64 KB, 256 thr: large-M, Cout = 128
+    {192, 256, 64, 2, 4, 2, 6, 0},   // 3  112 KB, 512 thr: large-M, Cout % 256 == 0 (fewest L2->LDS bytes per flop)
+    {64, 128, 64, 2, 2, 2, 0, 0},    // 4  alternates kept for scripts/conv_bench.py sweeps
+    {64, 128, 64, 2, 2, 3, 0, 0},    // 5
+    {64, 64, 64, 2, 2, 4, 0, 0},     // 6
+    {128, 128, 64, 2, 2, 2, 0, 0},   // 7
+    {128, 64, 64, 2, 2, 2, 0, 0},    // 8
+    {64, 256, 64, 2, 2, 2, 0, 0},    // 9
+    {128, 256, 64, 2, 4, 2, 0, 0},   // 10
+    {256, 128, 64, 4, 2, 3, 6, 0},   // 11
+    {192, 256, 64, 2, 4, 2, 3, 0},   // 12 ablation: no loads in the K loop
+    {192, 256, 64, 2, 4, 2, 4, 0},   // 13 ablation: loads only
+    {192, 256, 64, 2, 4, 2, 7, 0},   // 14 ablation: MFMA only
+    {192, 256, 64, 2, 4, 2, 8, 0},   // 15 ablation: LDS fragment reads only
+    {64, 64, 64, 2, 2, 2, 0, 2},     // 16 trace builds of 0, 1, 6, 3
+    {64, 128, 64, 2, 2, 2, 6, 2},    // 17
+    {64, 64, 64, 2, 2, 4, 0, 2},     // 18
+    {192, 256, 64, 2, 4, 2, 6, 2},   // 19
+    {64, 64, 64, 2, 2, 2, 4, 2},     // 20 traced ablations of the small tile: loads only (2- and 4-deep ring)
+    {64, 64, 64, 2, 2, 4, 4, 2},     // 21
+    {64, 64, 64, 2, 2, 2, 3, 2},     // 22 no loads in the K loop
+    {64, 64, 64, 2, 2, 4, 3, 2},     // 23
+    {64, 64, 64, 2, 2, 2, 0, 0, 4},  // 24 in-workgroup split-K: 4 groups x 4 waves, 128 KB
+    {64, 64, 64, 2, 2, 2, 0, 0, 2},  // 25 2 groups x 4 waves, 64 KB
+    {64, 128, 64, 2, 2, 2, 6, 0, 2}, // 26 2 groups x 4 waves, 96 KB
+    {64, 128, 64, 2, 2, 2, 0, 0, 2}, // 27
+    {128, 128, 64, 2, 2, 2, 6, 0, 2},  // 28 2 groups x 4 waves, 128 KB
+    {64, 64, 64, 2, 2, 2, 0, 2, 4},  // 29 trace build of 24
+    {64, 64, 64, 2, 2, 2, 6, 0, 4},  // 30
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
-static int choose_cfg(int maxM, int ngemm) {
+static int choose_cfg(int maxM, int ngemm, int kgemm) {
   if (const char* env = getenv("TDN_GEMM_CFG")) {
     const int id = atoi(env);
     if (id >= 0 && id < kNumCfgs && ngemm % kCfgs[id].bn == 0) return id;
@@ -524,118 +486,102 @@ static int choose_cfg(int maxM, int ngemm) {
   // Measured on MI355X over the R50-FPN shapes (scripts/conv_bench.py; profiles/convbench_*.log): several small
   // co-resident workgroups per CU (64-pixel tiles, 2-deep ring, 32-48 KB LDS) beat one large deeply pipelined
   // workgroup on almost every shape; only the very large-M 3x3 convs prefer the 256x128 8-wave tile.
-  if (ngemm % 256 == 0 && maxM >= 24000) return 61;   // 192x256, 8 waves: fewest L2->LDS bytes per flop
+  if (ngemm % 256 == 0 && maxM >= 24000) return 3;   // 192x256, 8 waves: fewest L2->LDS bytes per flop
+  // few tiles and a long K loop (layer4, the top FPN levels): every CU holds at most two 4-wave workgroups and the
+  // LDS-DMA stream starves (~4 B/clk per loading wave) — recruit a second wave group along K (in-workgroup split-K)
+  if ((long)ceil_div(maxM, 64) * (ngemm / 64) <= 512 && kgemm >= 2048) return 25;
   if (ngemm % 128 == 0) {
-    if (maxM >= 100000) return 63;
+    if (maxM >= 100000) return 2;
     const long t64 = (long)ceil_div(maxM, 64) * (ngemm / 128);
-    return t64 >= 300 ? 62 : 19;
+    return t64 >= 300 ? 1 : 0;
   }
-  return 19;
+  return 0;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0, int TAG = 0>
+static unsigned long long* g_trace_buf = nullptr;
+static long long g_trace_bytes = 0;
+
+// Diagnostics: TAG-2 kernel instantiations (TDN_GEMM_CFG >= 80) write 32 x 8-byte cycle stamps per workgroup here.
+extern "C" int tdn_debug_trace(void* buf, long long bytes) {
+  g_trace_buf = (unsigned long long*)buf;
+  g_trace_bytes = bytes;
+  return 0;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0, int TAG = 0, int KG = 1>
 static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   p.tiles_n = p.Cout / BN;
+  p.trace = nullptr;
   {
     const char* kr = getenv("TDN_KROT");
     p.krot = (kr && kr[0] == '1') ? 1 : 0;   // measured: no gain (profiles/), off keeps results tile-independent
   }
   const int ntiles = ceil_div(maxM, BM) * p.tiles_n;
   p.nwg_pad = (ntiles + 7) & ~7;
-  constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 2;
+  constexpr size_t lds = (size_t)KG * NSTAGE * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
     attr_set = true;
+    if (getenv("TDN_DEBUG_OCC")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &nb, (const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG>, WM * WN * KG * 64, lds);
+      fprintf(stderr, "[tdn] conv_gemm<%d,%d,%d,%d,%d,%d,%d,%d,%d>: %d B LDS, %d workgroups/CU\n", BM, BN, BK, WM,
+              WN, NSTAGE, MODE, TAG, KG, (int)lds, nb);
+    }
   }
-  dim3 grid(p.nwg_pad, p.ncls, 1), block(WM * WN * 64, 1, 1);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG>), grid, block, lds, stream, p);
+  if (TAG == 2) {
+    TDN_CHECK(g_trace_buf && (long long)p.nwg_pad * p.ncls * 256 <= g_trace_bytes,
+              "trace config selected but tdn_debug_trace() buffer is missing or too small");
+    p.trace = g_trace_buf;
+  }
+  dim3 grid(p.nwg_pad, p.ncls, 1), block(WM * WN * KG * 64, 1, 1);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG>), grid, block, lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
 static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   if (maxM <= 0) return 0;
-  switch (choose_cfg(maxM, p.Cout)) {
-    case 0: return launch_gemm<128, 128, 64, 2, 2, 2>(p, maxM, stream);
-    case 1: return launch_gemm<128, 128, 64, 2, 2, 3>(p, maxM, stream);
-    case 2: return launch_gemm<128, 128, 64, 2, 2, 4>(p, maxM, stream);
-    case 3: return launch_gemm<256, 128, 64, 4, 2, 3>(p, maxM, stream);
-    case 4: return launch_gemm<256, 128, 64, 4, 2, 2>(p, maxM, stream);
-    case 5: return launch_gemm<128, 64, 64, 2, 2, 3>(p, maxM, stream);
-    case 6: return launch_gemm<128, 64, 64, 2, 2, 4>(p, maxM, stream);
-    case 7: return launch_gemm<64, 128, 64, 2, 2, 4>(p, maxM, stream);
-    case 8: return launch_gemm<64, 128, 64, 2, 2, 3>(p, maxM, stream);
-    case 9: return launch_gemm<64, 64, 64, 2, 2, 4>(p, maxM, stream);
-    case 10: return launch_gemm<256, 64, 64, 4, 2, 3>(p, maxM, stream);
-    case 11: return launch_gemm<128, 128, 64, 2, 4, 3>(p, maxM, stream);
-    case 12: return launch_gemm<128, 128, 64, 2, 2, 2, 1>(p, maxM, stream);
-    case 13: return launch_gemm<128, 128, 64, 2, 2, 3, 1>(p, maxM, stream);
-    case 14: return launch_gemm<256, 128, 64, 4, 2, 3, 1>(p, maxM, stream);
-    case 15: return launch_gemm<256, 128, 64, 4, 2, 2, 1>(p, maxM, stream);
-    case 16: return launch_gemm<64, 128, 64, 2, 2, 3, 1>(p, maxM, stream);
-    case 17: return launch_gemm<64, 128, 64, 2, 2, 2, 0>(p, maxM, stream);
-    case 18: return launch_gemm<128, 64, 64, 2, 2, 2, 0>(p, maxM, stream);
-    case 19: return launch_gemm<64, 64, 64, 2, 2, 2, 0>(p, maxM, stream);
-    case 20: return launch_gemm<64, 128, 32, 2, 2, 2, 0>(p, maxM, stream);
-    case 21: return launch_gemm<64, 128, 32, 2, 2, 3, 0>(p, maxM, stream);
-    case 22: return launch_gemm<64, 128, 32, 2, 2, 4, 0>(p, maxM, stream);
-    case 23: return launch_gemm<128, 128, 32, 2, 2, 2, 0>(p, maxM, stream);
-    case 24: return launch_gemm<128, 128, 32, 2, 2, 3, 0>(p, maxM, stream);
-    case 25: return launch_gemm<32, 128, 64, 1, 4, 2, 0>(p, maxM, stream);
-    case 26: return launch_gemm<64, 256, 64, 2, 2, 2, 0>(p, maxM, stream);
-    case 27: return launch_gemm<128, 256, 64, 2, 2, 2, 0>(p, maxM, stream);
-    case 28: return launch_gemm<64, 128, 64, 2, 2, 2, 2>(p, maxM, stream);
-    case 29: return launch_gemm<128, 128, 64, 2, 2, 2, 2>(p, maxM, stream);
-    case 30: return launch_gemm<256, 128, 64, 4, 2, 3, 2>(p, maxM, stream);
-    case 31: return launch_gemm<64, 64, 64, 2, 2, 2, 2>(p, maxM, stream);
-    case 32: return launch_gemm<256, 256, 32, 2, 4, 4, 0>(p, maxM, stream);
-    case 33: return launch_gemm<256, 256, 64, 2, 4, 2, 0>(p, maxM, stream);
-    case 34: return launch_gemm<192, 256, 64, 2, 4, 2, 0>(p, maxM, stream);
-    case 35: return launch_gemm<256, 256, 32, 2, 4, 4, 2>(p, maxM, stream);
-    case 36: return launch_gemm<256, 128, 32, 4, 2, 4, 0>(p, maxM, stream);
-    case 37: return launch_gemm<128, 256, 64, 2, 4, 2, 0>(p, maxM, stream);
-    case 38: return launch_gemm<192, 256, 64, 2, 4, 2, 3>(p, maxM, stream);
-    case 39: return launch_gemm<192, 256, 64, 2, 4, 2, 4>(p, maxM, stream);
-    case 40: return launch_gemm<192, 256, 64, 2, 4, 2, 2>(p, maxM, stream);
-    case 41: return launch_gemm<192, 256, 64, 2, 4, 2, 1>(p, maxM, stream);
-    case 42: return launch_gemm<192, 128, 64, 2, 4, 2, 0>(p, maxM, stream);
-    case 43: return launch_gemm<192, 128, 64, 2, 2, 2, 0>(p, maxM, stream);
-    case 44: return launch_gemm<256, 256, 32, 2, 4, 4, 4>(p, maxM, stream);
-    case 45: return launch_gemm<128, 256, 32, 2, 4, 6, 4>(p, maxM, stream);
-    case 46: return launch_gemm<64, 128, 64, 2, 2, 2, 4>(p, maxM, stream);
-    case 47: return launch_gemm<128, 256, 32, 2, 4, 6, 0>(p, maxM, stream);
-    case 48: return launch_gemm<128, 256, 32, 2, 4, 4, 0>(p, maxM, stream);
-    case 49: return launch_gemm<256, 128, 32, 4, 2, 5, 0>(p, maxM, stream);
-    case 50: return launch_gemm<256, 256, 64, 4, 4, 2, 0>(p, maxM, stream);
-    case 51: return launch_gemm<128, 256, 64, 2, 8, 2, 0>(p, maxM, stream);
-    case 52: return launch_gemm<256, 128, 64, 4, 4, 2, 0>(p, maxM, stream);
-    case 53: return launch_gemm<256, 256, 64, 4, 4, 2, 4>(p, maxM, stream);
-    case 54: return launch_gemm<256, 256, 64, 4, 4, 2, 3>(p, maxM, stream);
-    case 55: return launch_gemm<192, 256, 64, 2, 4, 2, 5>(p, maxM, stream);
-    case 56: return launch_gemm<256, 256, 64, 2, 4, 2, 5>(p, maxM, stream);
-    case 57: return launch_gemm<128, 256, 64, 2, 4, 2, 5>(p, maxM, stream);
-    case 58: return launch_gemm<128, 128, 64, 2, 4, 2, 5>(p, maxM, stream);
-    case 59: return launch_gemm<256, 128, 64, 2, 4, 2, 5>(p, maxM, stream);
-    case 60: return launch_gemm<64, 128, 64, 2, 4, 2, 5>(p, maxM, stream);
-    case 61:
+  switch (choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap)) {
+    case 0: return launch_gemm<64, 64, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 1: return launch_gemm<64, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
+    case 2: return launch_gemm<128, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
+    case 3:
       if (maxM >= 100000 && p.Cout == 256 && p.cls[0].ntaps * p.Ktap == 2304 && !getenv("TDN_GEMM_CFG"))
         return launch_gemm<192, 256, 64, 2, 4, 2, 6, 1>(p, maxM, stream);
       return launch_gemm<192, 256, 64, 2, 4, 2, 6>(p, maxM, stream);
-    case 62: return launch_gemm<64, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
-    case 63: return launch_gemm<128, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
-    case 64: return launch_gemm<256, 128, 64, 4, 2, 3, 6>(p, maxM, stream);
-    case 65: return launch_gemm<192, 256, 64, 2, 4, 2, 7>(p, maxM, stream);
-    case 66: return launch_gemm<192, 256, 64, 2, 4, 2, 8>(p, maxM, stream);
-    case 67: return launch_gemm<64, 128, 64, 2, 4, 2, 0>(p, maxM, stream);
-    case 68: return launch_gemm<128, 64, 64, 2, 4, 2, 0>(p, maxM, stream);
-    case 69: return launch_gemm<64, 128, 64, 2, 4, 3, 0>(p, maxM, stream);
-    case 70: return launch_gemm<128, 128, 64, 4, 4, 2, 0>(p, maxM, stream);
-    case 71: return launch_gemm<64, 64, 64, 2, 4, 2, 0>(p, maxM, stream);
-    case 72: return launch_gemm<64, 128, 64, 2, 4, 2, 4>(p, maxM, stream);
-    default: return launch_gemm<128, 128, 64, 4, 4, 2, 4>(p, maxM, stream);
+    case 4: return launch_gemm<64, 128, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 5: return launch_gemm<64, 128, 64, 2, 2, 3, 0>(p, maxM, stream);
+    case 6: return launch_gemm<64, 64, 64, 2, 2, 4, 0>(p, maxM, stream);
+    case 7: return launch_gemm<128, 128, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 8: return launch_gemm<128, 64, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 9: return launch_gemm<64, 256, 64, 2, 2, 2, 0>(p, maxM, stream);
+    case 10: return launch_gemm<128, 256, 64, 2, 4, 2, 0>(p, maxM, stream);
+    case 11: return launch_gemm<256, 128, 64, 4, 2, 3, 6>(p, maxM, stream);
+    case 12: return launch_gemm<192, 256, 64, 2, 4, 2, 3>(p, maxM, stream);
+    case 13: return launch_gemm<192, 256, 64, 2, 4, 2, 4>(p, maxM, stream);
+    case 14: return launch_gemm<192, 256, 64, 2, 4, 2, 7>(p, maxM, stream);
+    case 15: return launch_gemm<192, 256, 64, 2, 4, 2, 8>(p, maxM, stream);
+    case 16: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 2>(p, maxM, stream);
+    case 17: return launch_gemm<64, 128, 64, 2, 2, 2, 6, 2>(p, maxM, stream);
+    case 18: return launch_gemm<64, 64, 64, 2, 2, 4, 0, 2>(p, maxM, stream);
+    case 19: return launch_gemm<192, 256, 64, 2, 4, 2, 6, 2>(p, maxM, stream);
+    case 20: return launch_gemm<64, 64, 64, 2, 2, 2, 4, 2>(p, maxM, stream);
+    case 21: return launch_gemm<64, 64, 64, 2, 2, 4, 4, 2>(p, maxM, stream);
+    case 22: return launch_gemm<64, 64, 64, 2, 2, 2, 3, 2>(p, maxM, stream);
+    case 23: return launch_gemm<64, 64, 64, 2, 2, 4, 3, 2>(p, maxM, stream);
+    case 24: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 4>(p, maxM, stream);
+    case 25: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 2>(p, maxM, stream);
+    case 26: return launch_gemm<64, 128, 64, 2, 2, 2, 6, 0, 2>(p, maxM, stream);
+    case 27: return launch_gemm<64, 128, 64, 2, 2, 2, 0, 0, 2>(p, maxM, stream);
+    case 28: return launch_gemm<128, 128, 64, 2, 2, 2, 6, 0, 2>(p, maxM, stream);
+    case 29: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 2, 4>(p, maxM, stream);
+    case 30: return launch_gemm<64, 64, 64, 2, 2, 2, 6, 0, 4>(p, maxM, stream);
+    default: TDN_CHECK(false, "bad GEMM config id"); return -1;
   }
 }
 
@@ -773,7 +719,7 @@ extern "C" int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout,
   int maxM;
   if (kind == 0) { build_fwd(p, N, H, W, Cin, Cout, k, stride, pad); maxM = p.cls[0].M; }
   else maxM = build_dgrad(p, N, H, W, Cin, Cout, k, stride, pad);
-  const GemmCfg& t = kCfgs[choose_cfg(maxM, p.Cout)];
+  const GemmCfg& t = kCfgs[choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap)];
   int Mtot = 0, taps_tot = 0;
   for (int i = 0; i < p.ncls; ++i) { Mtot += p.cls[i].M; taps_tot += p.cls[i].ntaps; }
   o[0] = Mtot; o[1] = p.Cout; o[2] = p.cls[0].ntaps * p.Ktap; o[3] = t.bm; o[4] = t.bn; o[5] = t.bk;
