@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--batch-per-gpu", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"],
+                    help="operand type; f16 + --depth 101 --batch-per-gpu 4 = SURVEY §8(d) config C5 "
+                         "(cotangents x1024: static loss scale)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=32)
@@ -180,6 +183,8 @@ def main():
 
     from torch_detection_amd import dp, ops
     backbone, neck = build_models(args.depth, device)
+    cdtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    backbone.compute_dtype = neck.compute_dtype = cdtype
     if world > 1:   # identical weights everywhere: broadcast rank 0's
         for p in list(backbone.state_dict().values()) + list(neck.state_dict().values()):
             dist.broadcast(p, 0)
@@ -193,11 +198,13 @@ def main():
     g2 = torch.Generator(device="cpu").manual_seed(2)
     # cotangents in the layout the outputs have (NCHW-shaped, channels_last strides), as a head consuming the
     # pyramid on this path would hand them back
-    cots = [(torch.randn(o.shape, generator=g2) / o[0].numel()).to(device=device, dtype=o.dtype)
+    loss_scale = 1024.0 if args.dtype == "f16" else 1.0
+    cots = [(torch.randn(o.shape, generator=g2) * (loss_scale / o[0].numel())).to(device=device, dtype=o.dtype)
             .contiguous(memory_format=torch.channels_last) for o in outs]
     del outs
 
-    reducer = dp.attach_reducer([neck, backbone], bucket_bytes=args.bucket_mb << 20) if world > 1 else None
+    reducer = dp.attach_reducer([neck, backbone], bucket_bytes=args.bucket_mb << 20, dtype=cdtype) \
+        if world > 1 else None
     params = list(backbone.parameters()) + list(neck.parameters())
 
     def step():
@@ -293,7 +300,7 @@ def main():
                       "images/sec ResNet-%d-FPN fwd+bwd 1333x800" % args.depth,
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "ResNet-%d + FPN(256, 5 levels) forward+backward, %d x 3x800x1344 "
                                    "(1333x800 zero-padded to /32) per GPU, BN eval (reference default), fixed "
                                    "cotangents, all parameter grads%s" %

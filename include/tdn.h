@@ -13,11 +13,15 @@
  *   - All tensors are caller-owned device memory (PyTorch allocations).  The
  *     library never allocates, frees or synchronises; every kernel is enqueued
  *     on the hipStream_t passed as `stream` (void*; NULL = default stream).
- *   - Activations / gradients are NHWC ("channels last"), dtype TDN_BF16
- *     (2-byte bfloat16).  Weights are pre-packed K-major by tdn_pack_conv_weight.
+ *   - Activations / gradients are NHWC ("channels last"), 2-byte elements: the
+ *     `dtype` argument says which — TDN_BF16 (bfloat16) or TDN_F16 (IEEE half;
+ *     the reference's model.half()).  Every 16-bit operand of one call has that
+ *     type; accumulation, BN/bias constants and all parameter gradients are fp32.
+ *     Weights are pre-packed K-major in the same type by tdn_pack_conv_weight.
  *   - Return value: 0 = ok, negative = error; tdn_last_error() returns a
  *     thread-local message.  Nothing throws across the boundary.
- *   - Re-entrant: no global mutable state besides the thread-local error text.
+ *   - Re-entrant: no global mutable state besides the thread-local error text
+ *     (and the optional diagnostics buffer of tdn_debug_trace).
  */
 #ifndef TDN_H_
 #define TDN_H_
@@ -31,7 +35,7 @@ extern "C" {
 
 #define TDN_VERSION 100 /* 0.1.0 */
 
-enum { TDN_BF16 = 0 };
+enum { TDN_BF16 = 0, TDN_F16 = 1 };
 
 /* epilogue addend modes */
 enum {

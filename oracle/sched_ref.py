@@ -22,7 +22,11 @@ from .torch_ref import ARCH, BN_EPS
 
 
 def rnd(t, quant):
-    return t.bfloat16().float() if quant else t
+    """Round to the storage type of the HIP path: ``quant`` is False (no rounding), True (bfloat16) or a torch
+    16-bit float dtype (torch.bfloat16 / torch.float16)."""
+    if not quant:
+        return t
+    return t.to(torch.bfloat16 if quant is True else quant).float()
 
 
 class Unit(object):

@@ -22,7 +22,8 @@ def nchw(t):
     return t.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
-def run_teacher_forced(T, depth, shape, dev="cuda", threads=None):
+def run_teacher_forced(T, depth, shape, dev="cuda", threads=None, dtype=torch.bfloat16, cot_scale=1.0,
+                       res_gain=1.0):
     """Returns a dict of measured relative-L2 errors (forward in situ, backward teacher-forced, and the plain
     end-to-end distances to the fp32 autograd oracle for the record)."""
     from oracle import sched_ref as S
@@ -33,10 +34,16 @@ def run_teacher_forced(T, depth, shape, dev="cuda", threads=None):
     rb, rf = T.ResNet(depth), T.FPN(chans, 256, 5)
     sdb = fill_state_dict(rb.state_dict(), 50)
     sdf = fill_state_dict(rf.state_dict(), 51)
+    if res_gain != 1.0:   # damp every residual branch (its last BN's gamma): keeps a deep net inside fp16's range
+        last_bn = "bn2.weight" if depth < 50 else "bn3.weight"
+        for k in sdb:
+            if k.endswith(last_bn):
+                sdb[k] = sdb[k] * res_gain
     rb.load_state_dict(sdb)
     rf.load_state_dict(sdf)
     rb.to(dev).train()
     rf.to(dev)
+    rb.compute_dtype = rf.compute_dtype = dtype   # bf16 (default) or fp16 operands; parameters stay fp32
     x = det_tensor(shape, 700, -2, 2)
     cap = {}
     HF.DEBUG_CAPTURE = cap
@@ -44,8 +51,10 @@ def run_teacher_forced(T, depth, shape, dev="cuda", threads=None):
         outs = rf(rb(x.to(dev)))
     finally:
         HF.DEBUG_CAPTURE = None
-    cots = [det_tensor(tuple(o.shape), 710 + i, -1, 1) for i, o in enumerate(outs)]
+    # cot_scale: the loss scale of an fp16 run (a power of two, so the cotangents stay exactly representable)
+    cots = [det_tensor(tuple(o.shape), 710 + i, -1, 1) * cot_scale for i, o in enumerate(outs)]
     torch.autograd.backward(outs, [c.to(dev).to(o.dtype) for c, o in zip(cots, outs)])
+    assert all(o.dtype == dtype for o in outs), [o.dtype for o in outs]
     got = {}
     for prefix, mod in (("backbone.", rb), ("neck.", rf)):
         for k, p in mod.named_parameters():
@@ -58,10 +67,10 @@ def run_teacher_forced(T, depth, shape, dev="cuda", threads=None):
     g_lat = [nchw(t) for t in lat]
     g_outs = [o.detach().float().cpu() for o in outs]
 
-    sch = S.Sched(sdb, sdf, depth, 5, quant=True)
+    sch = S.Sched(sdb, sdf, depth, 5, quant=dtype)
     fwd = {}
     # ---- forward, launch by launch, from the GPU's own inputs ----
-    fwd["stem"] = rel_l2(g_s, sch.stem.fwd(S.rnd(x, True), relu=True))
+    fwd["stem"] = rel_l2(g_s, sch.stem.fwd(S.rnd(x, dtype), relu=True))
     fwd["maxpool"] = rel_l2(g_saved[0][0], F.max_pool2d(g_s, 3, 2, 1))
     worst_blk = 0.0
     for blk, (bx, h1, h2, out) in zip(sch.blocks, g_saved):
@@ -83,7 +92,7 @@ def run_teacher_forced(T, depth, shape, dev="cuda", threads=None):
     worst = max(worst, rel_l2(g_outs[4], g_outs[3][:, :, ::2, ::2]))
     fwd["fpn_worst"] = worst
     # ---- backward with the GPU's saved activations ----
-    sch.x = S.rnd(x, True)
+    sch.x = S.rnd(x, dtype)
     sch.out_shapes = [tuple(o.shape) for o in g_outs]
     sch.load_saved(g_s, g_saved, g_lat)
     ref_grads = sch.backward(cots)

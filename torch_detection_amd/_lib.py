@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtdn.so")
 
 TDN_BF16 = 0
+TDN_F16 = 1
 ADD_NONE, ADD_SAME, ADD_UP2X, ADD_SUMPOOL2 = 0, 1, 2, 3
 
 c_void_p = ctypes.c_void_p

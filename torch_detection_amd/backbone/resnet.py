@@ -17,6 +17,7 @@ There is no CPU fallback: ``forward`` on a CPU tensor raises RuntimeError.
 """
 import logging
 
+import torch
 import torch.nn as nn
 
 from .. import functional as HF
@@ -34,20 +35,20 @@ class _ResBlock(nn.Module):
     def _norms(self):
         return [getattr(self, n) for n in self.norm_names]
 
-    def hip_spec(self):
+    def hip_spec(self, dtype=torch.bfloat16):
         if self.use_gn:
             raise NotImplementedError('GroupNorm residual blocks are not on the HIP path yet (SURVEY §8(f) row 2)')
         norms = self._norms()
         convs = [self.conv1, self.conv2] + ([self.conv3] if self._kind == 'bottleneck' else [])
-        us = [HF.prepare_unit(self, 'u%d' % i, c, n) for i, (c, n) in enumerate(zip(convs, norms))]
+        us = [HF.prepare_unit(self, 'u%d' % i, c, n, False, dtype) for i, (c, n) in enumerate(zip(convs, norms))]
         ud = None
         if self.downsample is not None:
-            ud = HF.prepare_unit(self, 'ud', self.downsample[0], self.downsample[1])
+            ud = HF.prepare_unit(self, 'ud', self.downsample[0], self.downsample[1], False, dtype)
         u3 = us[2] if self._kind == 'bottleneck' else None
         return HF.BlockSpec(self._kind, us[0], us[1], u3, ud, self.stride)
 
     def forward(self, x):
-        net = HF.SeqNet(None, [self.hip_spec()], [0])
+        net = HF.SeqNet(None, [self.hip_spec(HF.pick_dtype(self, x))], [0])
         return HF.SeqNetFunction.apply(net, x, *net.params())[0]
 
 
@@ -180,23 +181,26 @@ class ResNet(nn.Module):
             raise TypeError('pretrained must be a str or None')
 
     # ---- HIP schedule -------------------------------------------------------------------------------
-    def hip_net(self):
-        """Prepared whole-backbone program (units are cached on the blocks; only changed weights are re-packed)."""
+    def hip_net(self, dtype=None):
+        """Prepared whole-backbone program (units are cached on the blocks; only changed weights are re-packed).
+        ``dtype``: torch.bfloat16 / torch.float16 operands; default = ``self.compute_dtype`` (bfloat16)."""
+        if dtype is None:
+            dtype = getattr(self, 'compute_dtype', torch.bfloat16)
         if self.use_gn:
             raise NotImplementedError('ResNet(use_gn=True) is not on the HIP path yet (SURVEY §8(f) row 2)')
         if any(d != 1 for d in self.dilations):
             raise NotImplementedError('dilated ResNet stages are not on the HIP path yet')
-        stem = HF.prepare_unit(self, 'stem', self.conv1, getattr(self, self.norm_name), relu=True)
+        stem = HF.prepare_unit(self, 'stem', self.conv1, getattr(self, self.norm_name), True, dtype)
         blocks, out_blocks = [], []
         for i, layer_name in enumerate(self.res_layers):
             for blk in getattr(self, layer_name):
-                blocks.append(blk.hip_spec())
+                blocks.append(blk.hip_spec(dtype))
             if i in self.out_indices:
                 out_blocks.append(len(blocks) - 1)
         return HF.SeqNet(stem, blocks, out_blocks)
 
     def forward(self, x):
-        net = self.hip_net()
+        net = self.hip_net(HF.pick_dtype(self, x))
         outs = HF.SeqNetFunction.apply(net, x, *net.params())
         return outs[0] if len(outs) == 1 else tuple(outs)
 

@@ -226,7 +226,7 @@ extern "C" int tdn_nms(const float* boxes, const float* scores, int N, float iou
   TDN_CHECK(N >= 0 && N <= 64 * 8000, "tdn_nms: N=%d out of range (0..512000)", N);
   TDN_CHECK(num_kept != nullptr, "tdn_nms: NULL num_kept");
   if (N == 0) {
-    hipMemsetAsync(num_kept, 0, sizeof(int32_t), st);
+    (void)hipMemsetAsync(num_kept, 0, sizeof(int32_t), st);
     return 0;
   }
   TDN_CHECK(boxes && scores && keep && kept_idx && workspace, "tdn_nms: NULL pointer");
@@ -238,7 +238,7 @@ extern "C" int tdn_nms(const float* boxes, const float* scores, int N, float iou
   int* order = (int*)ws; ws += align256((int64_t)N * 4);
   float* sboxes = (float*)ws; ws += align256((int64_t)N * 16);
   unsigned long long* mask = (unsigned long long*)ws;
-  hipMemsetAsync(rank, 0, (size_t)N * 4, st);
+  (void)hipMemsetAsync(rank, 0, (size_t)N * 4, st);
   const int nb = (N + 255) / 256;
   int jsplit = 1024 / nb;  // aim for ~1024 blocks
   if (jsplit < 1) jsplit = 1;

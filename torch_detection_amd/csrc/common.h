@@ -35,9 +35,60 @@ void tdn_set_error(const char* fmt, ...);
     }                                                                   \
   } while (0)
 
+#define TDN_CHECK_DTYPE(dtype) \
+  TDN_CHECK((dtype) == TDN_BF16 || (dtype) == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", (int)(dtype))
+// launch kernel<F16> chosen by the run-time dtype code
+#define TDN_LAUNCH_T(kernel, dtype, grid, block, stream, ...)                                  \
+  do {                                                                                         \
+    if ((dtype) == TDN_F16) hipLaunchKernelGGL(kernel<true>, grid, block, 0, stream, __VA_ARGS__);  \
+    else hipLaunchKernelGGL(kernel<false>, grid, block, 0, stream, __VA_ARGS__);                \
+  } while (0)
+
 // ---- small device helpers -------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }
+
+// 16-bit element type by template flag.  Tensors are carried as bf16_t* (a 2-byte element either way: addressing,
+// LDS-DMA, swizzles and transposing reads do not care); only the conversions and the MFMA opcode differ for
+// TDN_F16.  Both conversions round to nearest even, like PyTorch's .bfloat16() / .half().
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+
+template <bool F16>
+__device__ __forceinline__ float elem_to_f32(bf16_t raw) {
+  if constexpr (F16) return (float)__builtin_bit_cast(f16_t, raw);
+  else return (float)raw;
+}
+template <bool F16>
+__device__ __forceinline__ bf16_t f32_to_elem(float v) {
+  if constexpr (F16) return __builtin_bit_cast(bf16_t, (f16_t)v);
+  else return (bf16_t)v;
+}
+template <bool F16>
+__device__ __forceinline__ f32x4_t load4_f32(const bf16_t* p) {
+  const bf16x4_t r = *(const bf16x4_t*)p;
+  f32x4_t v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = elem_to_f32<F16>(r[e]);
+  return v;
+}
+template <bool F16>
+__device__ __forceinline__ void store4_f32(bf16_t* p, f32x4_t v) {
+  bf16x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f32_to_elem<F16>(v[e]);
+  *(bf16x4_t*)p = o;
+}
+// D = A(16 x 32) * B(32 x 16) + C on the matrix cores; operands are 8 consecutive k per lane
+template <bool F16>
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c,
+                                                  0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 // 16-byte async global -> LDS copy. LDS destination = wave-uniform `lds_base` + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {

@@ -78,7 +78,7 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // wave sustains only ~4 B/clk of LDS-DMA however many loads it keeps in flight, a CU needs ~16 loading waves to reach
 // its ~40 B/clk L2->LDS rate, and the small-M layers (layer3/4, FPN top levels) have too few output tiles to put
 // four 4-wave workgroups on every CU — so the extra waves are recruited along K instead.
-template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0, int TAG = 0, int KG = 1>
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0, int TAG = 0, int KG = 1, bool F16 = false>
 __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
   constexpr int NW = WM * WN;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     for (int i = 0; i < FN; ++i)
 #pragma unroll
       for (int j = 0; j < FM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma16<F16>(wf[i], xf[j], acc[i][j]);
   };
 
   // epilogue constants; with KG groups, fragment (i, j) is finished by group (i*FM + j) % KG
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
             for (int i = 0; i < FN; ++i)
 #pragma unroll
               for (int j = 0; j < FM; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<F16>(wf[i], xf[j], acc[i][j]);
           }
         }
       } else if constexpr (MODE == 8) {   // ABLATION: LDS fragment reads only (kept live), no MFMA, no loads
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
           for (int i = 0; i < FN; ++i)
 #pragma unroll
             for (int j = 0; j < FM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = mfma16<F16>(wf[kk][i], xf[kk][j], acc[i][j]);
         __builtin_amdgcn_sched_group_barrier(0x100, FN + FM, 0);
         __builtin_amdgcn_sched_group_barrier(0x20, LOADS, 0);
 #pragma unroll
@@ -387,18 +387,16 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
       f32x4_t v = fragment(i, j) * sc[i] + sh[i];
       if (p.addend_mode != TDN_ADD_NONE) {
         const bf16_t* ap = p.addend + apix * p.Cout + ch;
-        bf16x4_t r = *(const bf16x4_t*)ap;
+        const f32x4_t r = load4_f32<F16>(ap);
         if (p.addend_mode == TDN_ADD_SUMPOOL2) {
           // sum in a fixed order: (0,0) + (0,1) + (1,0) + (1,1)
-          bf16x4_t r1 = *(const bf16x4_t*)(ap + p.Cout);
-          bf16x4_t r2 = *(const bf16x4_t*)(ap + (int64_t)p.addend_w * p.Cout);
-          bf16x4_t r3 = *(const bf16x4_t*)(ap + (int64_t)(p.addend_w + 1) * p.Cout);
+          const f32x4_t r1 = load4_f32<F16>(ap + p.Cout);
+          const f32x4_t r2 = load4_f32<F16>(ap + (int64_t)p.addend_w * p.Cout);
+          const f32x4_t r3 = load4_f32<F16>(ap + (int64_t)(p.addend_w + 1) * p.Cout);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] += (((float)r[e] + (float)r1[e]) + (float)r2[e]) + (float)r3[e];
+          for (int e = 0; e < 4; ++e) v[e] += ((r[e] + r1[e]) + r2[e]) + r3[e];
         } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+          v += r;
         }
       }
       if (p.relu) {
@@ -406,17 +404,14 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if (p.mask) {
-        bf16x4_t mk = *(const bf16x4_t*)(p.mask + opix * p.Cout + ch);
+        const f32x4_t mk = load4_f32<F16>(p.mask + opix * p.Cout + ch);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ((float)mk[e] > 0.f) ? v[e] : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = (mk[e] > 0.f) ? v[e] : 0.f;
       }
       if (p.out_f32) {
         *(f32x4_t*)((float*)p.out + opix * p.Cout + ch) = v;
       } else {
-        bf16x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-        *(bf16x4_t*)(p.out + opix * p.Cout + ch) = o;
+        store4_f32<F16>(p.out + opix * p.Cout + ch, v);
       }
     }
   }
@@ -508,7 +503,7 @@ extern "C" int tdn_debug_trace(void* buf, long long bytes) {
   return 0;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0, int TAG = 0, int KG = 1>
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0, int TAG = 0, int KG = 1, bool F16 = false>
 static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   p.tiles_n = p.Cout / BN;
   p.trace = nullptr;
@@ -521,16 +516,16 @@ static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   constexpr size_t lds = (size_t)KG * NSTAGE * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG, F16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
     attr_set = true;
     if (getenv("TDN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &nb, (const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG>, WM * WN * KG * 64, lds);
-      fprintf(stderr, "[tdn] conv_gemm<%d,%d,%d,%d,%d,%d,%d,%d,%d>: %d B LDS, %d workgroups/CU\n", BM, BN, BK, WM,
-              WN, NSTAGE, MODE, TAG, KG, (int)lds, nb);
+          &nb, (const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG, F16>, WM * WN * KG * 64, lds);
+      fprintf(stderr, "[tdn] conv_gemm<%d,%d,%d,%d,%d,%d,%d,%d,%d,%s>: %d B LDS, %d workgroups/CU\n", BM, BN, BK, WM,
+              WN, NSTAGE, MODE, TAG, KG, F16 ? "f16" : "bf16", (int)lds, nb);
     }
   }
   if (TAG == 2) {
@@ -539,13 +534,24 @@ static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
     p.trace = g_trace_buf;
   }
   dim3 grid(p.nwg_pad, p.ncls, 1), block(WM * WN * KG * 64, 1, 1);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG, F16>), grid, block, lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
-static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
+static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype) {
   if (maxM <= 0) return 0;
+  if (dtype == TDN_F16) {   // fp16 operands: the production tile set only
+    const int id = choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap);
+    switch (id) {
+      case 0: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 1, true>(p, maxM, stream);
+      case 1: return launch_gemm<64, 128, 64, 2, 2, 2, 6, 0, 1, true>(p, maxM, stream);
+      case 2: return launch_gemm<128, 128, 64, 2, 2, 2, 6, 0, 1, true>(p, maxM, stream);
+      case 3: return launch_gemm<192, 256, 64, 2, 4, 2, 6, 0, 1, true>(p, maxM, stream);
+      case 25: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 2, true>(p, maxM, stream);
+      default: TDN_CHECK(false, "GEMM config %d (TDN_GEMM_CFG) has no TDN_F16 build", id); return -1;
+    }
+  }
   switch (choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap)) {
     case 0: return launch_gemm<64, 64, 64, 2, 2, 2, 0>(p, maxM, stream);
     case 1: return launch_gemm<64, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
@@ -612,7 +618,7 @@ static int fill_epilogue(GemmParams& p, const tdn_epilogue* ep, int Hout, int Wo
 }
 
 static int check_conv_shape(int N, int H, int W, int Cin, int Cout, int k, int stride, int pad, int dtype) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported (got dtype %d)", dtype);
+  TDN_CHECK(dtype == TDN_BF16 || dtype == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", dtype);
   TDN_CHECK(N > 0 && H > 0 && W > 0, "bad tensor shape N=%d H=%d W=%d", N, H, W);
   TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported (1 or 3)", k);
   TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported (1 or 2)", stride);
@@ -669,7 +675,7 @@ extern "C" int tdn_conv2d_fwd(const void* x, const void* w_fwd, void* y, int N, 
   build_fwd(p, N, H, W, Cin, Cout, k, stride, pad);
   p.in = (const bf16_t*)x; p.wt = (const bf16_t*)w_fwd; p.out = (bf16_t*)y;
   if (fill_epilogue(p, ep, p.Hout, p.Wout)) return -1;
-  return dispatch_gemm(p, p.cls[0].M, (hipStream_t)stream);
+  return dispatch_gemm(p, p.cls[0].M, (hipStream_t)stream, dtype);
 }
 
 extern "C" int tdn_conv2d_dgrad(const void* g, const void* w_dgrad, void* dx, int N, int H, int W, int Cin,
@@ -681,14 +687,14 @@ extern "C" int tdn_conv2d_dgrad(const void* g, const void* w_dgrad, void* dx, in
   const int maxM = build_dgrad(p, N, H, W, Cin, Cout, k, stride, pad);
   p.in = (const bf16_t*)g; p.wt = (const bf16_t*)w_dgrad; p.out = (bf16_t*)dx;
   if (fill_epilogue(p, ep, p.Hout, p.Wout)) return -1;
-  return dispatch_gemm(p, maxM, (hipStream_t)stream);
+  return dispatch_gemm(p, maxM, (hipStream_t)stream, dtype);
 }
 
 // Stem: 7x7 s2 p3 conv on the zero-padded NHWC4 staging buffer xp[N][H+6][W+8][4]. One "tap" per kernel
 // row kh: 8 consecutive pixels x 4 channels = 32 contiguous bf16 (kw = 7 and c = 3 carry zero weights).
 extern "C" int tdn_stem_conv_fwd(const void* xp, const void* w_stem, void* y, int N, int H, int W, int Cout,
                                  const tdn_epilogue* ep, int dtype, void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(dtype == TDN_BF16 || dtype == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", dtype);
   TDN_CHECK(xp && w_stem && y, "tdn_stem_conv_fwd: NULL tensor pointer");
   TDN_CHECK(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0 && N > 0, "stem needs even H, W (got %dx%d)", H, W);
   TDN_CHECK(Cout % 64 == 0, "stem Cout must be a multiple of 64");
@@ -701,6 +707,7 @@ extern "C" int tdn_stem_conv_fwd(const void* xp, const void* w_stem, void* y, in
   for (int kh = 0; kh < 7; ++kh) c.taps[kh] = pack_tap(kh, 0, kh);
   p.in = (const bf16_t*)xp; p.wt = (const bf16_t*)w_stem; p.out = (bf16_t*)y;
   if (fill_epilogue(p, ep, Ho, Wo)) return -1;
+  if (dtype == TDN_F16) return launch_gemm<128, 64, 32, 2, 2, 3, 0, 0, 1, true>(p, c.M, (hipStream_t)stream);
   return launch_gemm<128, 64, 32, 2, 2, 3>(p, c.M, (hipStream_t)stream);
 }
 

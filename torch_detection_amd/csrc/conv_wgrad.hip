@@ -34,7 +34,7 @@ __device__ __forceinline__ int tr_swz(int row) {
   else return (row >> 3) & 1;
 }
 
-template <int BMW /*co*/, int BNW /*ci*/, int WM = 2, int WN = 2>
+template <int BMW /*co*/, int BNW /*ci*/, int WM = 2, int WN = 2, bool F16 = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BKW = 64;                       // pixels per stage
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
   const bool do_colsum = (tile_k == 0) && (wn == 0);
   bf16x8_t ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+  for (int e = 0; e < 8; ++e) ones[e] = f32_to_elem<F16>(1.0f);
 
   const int T = (m_end > m_begin) ? ceil_div(m_end - m_begin, BKW) : 0;
   if (T > 0) {
@@ -192,11 +192,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], gf[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<F16>(xf[j], gf[i], acc[i][j]);
         if (do_colsum) {
 #pragma unroll
           for (int i = 0; i < FM; ++i)
-            acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, gf[i], acc1[i], 0, 0, 0);
+            acc1[i] = mfma16<F16>(ones, gf[i], acc1[i]);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
 // still use the whole block; split-lane partial sums are combined through LDS in lane order (deterministic).
 //   map_mode 0: dw index = co*Ktot + k  ([Cout][kh][kw][Cin] = channels_last view of the OIHW grad)
 //   map_mode 1: stem, k = (kh*8 + kw)*4 + c  ->  dw[co][c][kh][kw] contiguous (pads dropped)
+template <bool F16>
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ slab,
                                                              const float* __restrict__ colsum, int splitk,
                                                              int Cout, int Ktot, const bf16_t* __restrict__ w_fwd,
@@ -267,9 +268,9 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
     }
     if (active && spl == 0) {
       const int k = k4 * 4;
-      const bf16x4_t wv = *(const bf16x4_t*)(w_fwd + (int64_t)co * Ktot + k);
+      const f32x4_t wv = load4_f32<F16>(w_fwd + (int64_t)co * Ktot + k);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dot += (float)wv[e] * s[e];
+      for (int e = 0; e < 4; ++e) dot += wv[e] * s[e];
       if (map_mode == 0) {
         f32x4_t* o = (f32x4_t*)(dw + (int64_t)co * Ktot + k);
         f32x4_t v = s * sc;
@@ -355,26 +356,33 @@ static int64_t wgrad_ws_bytes(const WgradPlan& w, int Cout) {
   return ((int64_t)w.splitk * Cout * w.Ktot + (int64_t)w.splitk * Cout) * 4 + 256;
 }
 
-template <int BMW, int BNW, int WM = 2, int WN = 2>
-static int launch_wgrad(const WgradParams& p, hipStream_t stream) {
+template <int BMW, int BNW, int WM, int WN, bool F16>
+static int launch_wgrad_t(const WgradParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)64 * (BMW + BNW) * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, WM, WN>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, WM, WN, F16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
     attr_set = true;
   }
   const int slots = p.splitk >= 8 ? 8 * ((p.splitk + 7) / 8) : p.splitk;   // see the kernel's work map
   dim3 grid(slots * p.tiles_co * p.tiles_k, 1, 1), block(WM * WN * 64, 1, 1);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WM, WN>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WM, WN, F16>), grid, block, lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
+template <int BMW, int BNW, int WM = 2, int WN = 2>
+static int launch_wgrad(const WgradParams& p, hipStream_t stream, int dtype) {
+  return dtype == TDN_F16 ? launch_wgrad_t<BMW, BNW, WM, WN, true>(p, stream)
+                          : launch_wgrad_t<BMW, BNW, WM, WN, false>(p, stream);
+}
+
 static int run_wgrad(WgradParams& p, const WgradPlan& w, const void* w_fwd, const float* scale,
                      const float* mean, const float* invstd, float* dw, float* dgamma, float* dbeta,
-                     float beta, void* workspace, int64_t workspace_bytes, int map_mode, hipStream_t stream) {
+                     float beta, void* workspace, int64_t workspace_bytes, int map_mode, int dtype,
+                     hipStream_t stream) {
   TDN_CHECK(workspace_bytes >= wgrad_ws_bytes(w, p.Cout), "wgrad workspace too small: %lld < %lld",
             (long long)workspace_bytes, (long long)wgrad_ws_bytes(w, p.Cout));
   TDN_CHECK(((uintptr_t)workspace & 15) == 0, "wgrad workspace must be 16-byte aligned");
@@ -383,20 +391,25 @@ static int run_wgrad(WgradParams& p, const WgradPlan& w, const void* w_fwd, cons
   p.M = w.M; p.Mchunk = w.mchunk; p.splitk = w.splitk; p.Ktot = w.Ktot;
   p.tiles_co = w.tiles_co; p.tiles_k = w.tiles_k;
   int rc;
-  if (w.bmw == 256 && w.bnw == 128) rc = launch_wgrad<256, 128, 4, 2>(p, stream);
-  else if (w.bmw == 256 && w.bnw == 64) rc = launch_wgrad<256, 64, 4, 2>(p, stream);
-  else if (w.bmw == 128 && w.bnw == 128) rc = launch_wgrad<128, 128>(p, stream);
-  else if (w.bmw == 128 && w.bnw == 64) rc = launch_wgrad<128, 64>(p, stream);
-  else if (w.bmw == 64 && w.bnw == 128) rc = launch_wgrad<64, 128>(p, stream);
-  else if (w.bmw == 64 && w.bnw == 64) rc = launch_wgrad<64, 64>(p, stream);
-  else if (w.bmw == 64 && w.bnw == 32) rc = launch_wgrad<64, 32>(p, stream);
+  if (w.bmw == 256 && w.bnw == 128) rc = launch_wgrad<256, 128, 4, 2>(p, stream, dtype);
+  else if (w.bmw == 256 && w.bnw == 64) rc = launch_wgrad<256, 64, 4, 2>(p, stream, dtype);
+  else if (w.bmw == 128 && w.bnw == 128) rc = launch_wgrad<128, 128>(p, stream, dtype);
+  else if (w.bmw == 128 && w.bnw == 64) rc = launch_wgrad<128, 64>(p, stream, dtype);
+  else if (w.bmw == 64 && w.bnw == 128) rc = launch_wgrad<64, 128>(p, stream, dtype);
+  else if (w.bmw == 64 && w.bnw == 64) rc = launch_wgrad<64, 64>(p, stream, dtype);
+  else if (w.bmw == 64 && w.bnw == 32) rc = launch_wgrad<64, 32>(p, stream, dtype);
   else { tdn_set_error("wgrad: no kernel for tile %dx%d", w.bmw, w.bnw); return -1; }
   if (rc) return rc;
   int k4p = 1;
   while (k4p < (w.Ktot >> 2) && k4p < 256) k4p <<= 1;
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(p.Cout), dim3(256), 0, stream, p.slab, p.colsum, w.splitk,
-                     p.Cout, w.Ktot, (const bf16_t*)w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, map_mode,
-                     k4p);
+  if (dtype == TDN_F16)
+    hipLaunchKernelGGL(wgrad_finalize_kernel<true>, dim3(p.Cout), dim3(256), 0, stream, p.slab, p.colsum, w.splitk,
+                       p.Cout, w.Ktot, (const bf16_t*)w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, map_mode,
+                       k4p);
+  else
+    hipLaunchKernelGGL(wgrad_finalize_kernel<false>, dim3(p.Cout), dim3(256), 0, stream, p.slab, p.colsum, w.splitk,
+                       p.Cout, w.Ktot, (const bf16_t*)w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, map_mode,
+                       k4p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -424,7 +437,7 @@ extern "C" int tdn_conv2d_wgrad(const void* x, const void* g, const void* w_fwd,
                                 float* dbeta, float beta, int N, int H, int W, int Cin, int Cout, int k,
                                 int stride, int pad, void* workspace, int64_t workspace_bytes, int dtype,
                                 void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(dtype == TDN_BF16 || dtype == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", dtype);
   TDN_CHECK(x && g && w_fwd && dw && workspace, "tdn_conv2d_wgrad: NULL pointer");
   TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported", k);
   TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported", stride);
@@ -439,7 +452,7 @@ extern "C" int tdn_conv2d_wgrad(const void* x, const void* g, const void* w_fwd,
   for (int kh = 0; kh < k; ++kh)
     for (int kw = 0; kw < k; ++kw) p.taps[kh * k + kw] = (kh - pad + 64) | ((kw - pad + 64) << 8);
   return run_wgrad(p, w, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes, 0,
-                   (hipStream_t)stream);
+                   dtype, (hipStream_t)stream);
 }
 
 extern "C" int64_t tdn_stem_conv_wgrad_workspace(int N, int H, int W, int Cout) {
@@ -451,7 +464,7 @@ extern "C" int tdn_stem_conv_wgrad(const void* xp, const void* g, const void* w_
                                    const float* mean, const float* invstd, float* dw, float* dgamma,
                                    float* dbeta, float beta, int N, int H, int W, int Cout, void* workspace,
                                    int64_t workspace_bytes, int dtype, void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK(dtype == TDN_BF16 || dtype == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", dtype);
   TDN_CHECK(xp && g && w_stem && dw && workspace, "tdn_stem_conv_wgrad: NULL pointer");
   TDN_CHECK(H % 2 == 0 && W % 2 == 0 && Cout % 64 == 0, "stem wgrad: bad shape");
   const int Ho = H / 2, Wo = W / 2;
@@ -462,5 +475,5 @@ extern "C" int tdn_stem_conv_wgrad(const void* xp, const void* g, const void* w_
   p.ntaps = 7;
   for (int kh = 0; kh < 7; ++kh) p.taps[kh] = (kh + 64) | ((0 + 64) << 8);
   return run_wgrad(p, w, w_stem, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes, 1,
-                   (hipStream_t)stream);
+                   dtype, (hipStream_t)stream);
 }

@@ -46,6 +46,7 @@ extern "C" int tdn_bn_fold(const float* gamma, const float* beta, const float* m
 }
 
 // ---- weight packing --------------------------------------------------------------------------
+template <bool F16>
 __global__ void pack_weight_kernel(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int Cout,
                                    int Cin, int kh, int kw, const float* scale, bf16_t* w_fwd, bf16_t* w_dgrad) {
   const int64_t total = (int64_t)Cout * Cin * kh * kw;
@@ -58,12 +59,12 @@ __global__ void pack_weight_kernel(const float* w, int64_t s_o, int64_t s_i, int
     const int y = (int)(r % kh);
     const int co = (int)(r / kh);
     const float v = w[co * s_o + ci * s_i + y * s_h + x * s_w];
-    const bf16_t vb = (bf16_t)v;
+    const bf16_t vb = f32_to_elem<F16>(v);
     w_fwd[i] = vb;
     if (w_dgrad) {
       const float sc = scale ? scale[co] : 1.f;
       // dgrad operand uses the bf16-rounded forward weight times the fp32 scale
-      w_dgrad[(((int64_t)ci * kh + y) * kw + x) * Cout + co] = (bf16_t)((float)vb * sc);
+      w_dgrad[(((int64_t)ci * kh + y) * kw + x) * Cout + co] = f32_to_elem<F16>(elem_to_f32<F16>(vb) * sc);
     }
   }
 }
@@ -71,36 +72,38 @@ __global__ void pack_weight_kernel(const float* w, int64_t s_o, int64_t s_i, int
 extern "C" int tdn_pack_conv_weight(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int Cout,
                                     int Cin, int kh, int kw, const float* scale, void* w_fwd, void* w_dgrad,
                                     int dtype, void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(w && w_fwd, "tdn_pack_conv_weight: NULL pointer");
   const int64_t total = (int64_t)Cout * Cin * kh * kw;
   TDN_CHECK(total > 0, "tdn_pack_conv_weight: empty weight");
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, s_o, s_i,
+  TDN_LAUNCH_T(pack_weight_kernel, dtype, dim3(grid_for(total, 256)), dim3(256), (hipStream_t)stream, w, s_o, s_i,
                      s_h, s_w, Cout, Cin, kh, kw, scale, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
+template <bool F16>
 __global__ void pack_stem_kernel(const float* w, int Cout, bf16_t* w_fwd) {
   const int total = Cout * 7 * 8 * 4;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int c = i & 3, kw = (i >> 2) & 7, kh = (i >> 5) % 7, co = i / 224;
     float v = 0.f;
     if (c < 3 && kw < 7) v = w[co * 147 + c * 49 + kh * 7 + kw];
-    w_fwd[i] = (bf16_t)v;
+    w_fwd[i] = f32_to_elem<F16>(v);
   }
 }
 
 extern "C" int tdn_pack_stem_weight(const float* w, int Cout, void* w_fwd, int dtype, void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(w && w_fwd && Cout > 0, "tdn_pack_stem_weight: bad arguments");
-  hipLaunchKernelGGL(pack_stem_kernel, dim3(grid_for(Cout * 224, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout,
+  TDN_LAUNCH_T(pack_stem_kernel, dtype, dim3(grid_for(Cout * 224, 256)), dim3(256), (hipStream_t)stream, w, Cout,
                      (bf16_t*)w_fwd);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
 // ---- image staging: NCHW fp32 -> zero-padded NHWC4 bf16 [N][H+6][W+8][4] ----------------------
+template <bool F16>
 __global__ void stage_image_kernel(const float* img, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N,
                                    int H, int W, bf16_t* xp) {
   const int Hp = H + 6, Wp = W + 8;
@@ -111,12 +114,12 @@ __global__ void stage_image_kernel(const float* img, int64_t s_n, int64_t s_c, i
     const int hp = (int)(r % Hp);
     const int n = (int)(r / Hp);
     const int h = hp - 3, w = wp - 3;
-    bf16x4_t v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    bf16x4_t v = {f32_to_elem<F16>(0.f), f32_to_elem<F16>(0.f), f32_to_elem<F16>(0.f), f32_to_elem<F16>(0.f)};
     if (h >= 0 && h < H && w >= 0 && w < W) {
       const float* s = img + n * s_n + h * s_h + w * s_w;
-      v[0] = (bf16_t)s[0];
-      v[1] = (bf16_t)s[s_c];
-      v[2] = (bf16_t)s[2 * s_c];
+      v[0] = f32_to_elem<F16>(s[0]);
+      v[1] = f32_to_elem<F16>(s[s_c]);
+      v[2] = f32_to_elem<F16>(s[2 * s_c]);
     }
     *(bf16x4_t*)(xp + i * 4) = v;
   }
@@ -124,16 +127,17 @@ __global__ void stage_image_kernel(const float* img, int64_t s_n, int64_t s_c, i
 
 extern "C" int tdn_stage_image(const float* img, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N, int H,
                                int W, void* xp, int dtype, void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(img && xp && N > 0 && H > 0 && W > 0, "tdn_stage_image: bad arguments");
   const int64_t total = (int64_t)N * (H + 6) * (W + 8);
-  hipLaunchKernelGGL(stage_image_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, s_n,
+  TDN_LAUNCH_T(stage_image_kernel, dtype, dim3(grid_for(total, 256)), dim3(256), (hipStream_t)stream, img, s_n,
                      s_c, s_h, s_w, N, H, W, (bf16_t*)xp);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
 // ---- max pool 3x3 s2 p1 (NHWC, 8 channels per lane) --------------------------------------------
+template <bool F16>
 __global__ void maxpool_fwd_kernel(const bf16_t* x, bf16_t* y, uint8_t* idx, int N, int H, int W, int C, int Ho,
                                    int Wo) {
   const int C8 = C >> 3;
@@ -160,7 +164,7 @@ __global__ void maxpool_fwd_kernel(const bf16_t* x, bf16_t* y, uint8_t* idx, int
         const bf16x8_t v = *(const bf16x8_t*)(x + (((int64_t)n * H + h) * W + w) * C + c8 * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float f = (float)v[e];
+          const float f = elem_to_f32<F16>(v[e]);
           // PyTorch rule: first maximum in (kh, kw) scan order wins; NaN propagates
           if (bi[e] < 0 || f > best[e] || f != f) { best[e] = f; bi[e] = kh * 3 + kw; }
         }
@@ -169,7 +173,7 @@ __global__ void maxpool_fwd_kernel(const bf16_t* x, bf16_t* y, uint8_t* idx, int
     bf16x8_t o;
     uint64_t packed = 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { o[e] = (bf16_t)best[e]; packed |= (uint64_t)(uint8_t)bi[e] << (8 * e); }
+    for (int e = 0; e < 8; ++e) { o[e] = f32_to_elem<F16>(best[e]); packed |= (uint64_t)(uint8_t)bi[e] << (8 * e); }
     *(bf16x8_t*)(y + i * 8) = o;
     *(uint64_t*)(idx + i * 8) = packed;
   }
@@ -177,17 +181,18 @@ __global__ void maxpool_fwd_kernel(const bf16_t* x, bf16_t* y, uint8_t* idx, int
 
 extern "C" int tdn_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype,
                                     void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "tdn_maxpool3x3s2_fwd: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int64_t total = (int64_t)N * Ho * Wo * (C / 8);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  TDN_LAUNCH_T(maxpool_fwd_kernel, dtype, dim3(grid_for(total, 256)), dim3(256), (hipStream_t)stream,
                      (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
 // Gather form of the adjoint: each input element sums dy of the (<= 4) windows that selected it.
+template <bool F16>
 __global__ void maxpool_bwd_kernel(const bf16_t* dy, const uint8_t* idx, const bf16_t* mask, bf16_t* dx, int N, int H,
                                    int W, int C, int Ho, int Wo) {
   const int C8 = C >> 3;
@@ -215,17 +220,17 @@ __global__ void maxpool_bwd_kernel(const bf16_t* dy, const uint8_t* idx, const b
         const bf16x8_t g = *(const bf16x8_t*)(dy + o);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if ((int)((pk >> (8 * e)) & 0xff) == code) acc[e] += (float)g[e];
+          if ((int)((pk >> (8 * e)) & 0xff) == code) acc[e] += elem_to_f32<F16>(g[e]);
       }
     }
     bf16x8_t o8;
     if (mask) {
       const bf16x8_t mk = *(const bf16x8_t*)(mask + i * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)(((float)mk[e] > 0.f) ? acc[e] : 0.f);
+      for (int e = 0; e < 8; ++e) o8[e] = f32_to_elem<F16>((elem_to_f32<F16>(mk[e]) > 0.f) ? acc[e] : 0.f);
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)acc[e];
+      for (int e = 0; e < 8; ++e) o8[e] = f32_to_elem<F16>(acc[e]);
     }
     *(bf16x8_t*)(dx + i * 8) = o8;
   }
@@ -233,11 +238,11 @@ __global__ void maxpool_bwd_kernel(const bf16_t* dy, const uint8_t* idx, const b
 
 extern "C" int tdn_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, const void* mask_src, void* dx, int N,
                                     int H, int W, int C, int dtype, void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "tdn_maxpool3x3s2_bwd: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int64_t total = (int64_t)N * H * W * (C / 8);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  TDN_LAUNCH_T(maxpool_bwd_kernel, dtype, dim3(grid_for(total, 256)), dim3(256), (hipStream_t)stream,
                      (const bf16_t*)dy, idx, (const bf16_t*)mask_src, (bf16_t*)dx, N, H, W, C, Ho, Wo);
   TDN_LAUNCH_CHECK();
   return 0;
@@ -259,7 +264,7 @@ __global__ void subsample_fwd_kernel(const bf16_t* x, bf16_t* y, int N, int H, i
 }
 
 extern "C" int tdn_subsample2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "tdn_subsample2_fwd: bad arguments");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   hipLaunchKernelGGL(subsample_fwd_kernel, dim3(grid_for((int64_t)N * Ho * Wo * (C / 8), 256)), dim3(256), 0,
@@ -268,6 +273,7 @@ extern "C" int tdn_subsample2_fwd(const void* x, void* y, int N, int H, int W, i
   return 0;
 }
 
+template <bool F16>
 __global__ void subsample_bwd_kernel(const bf16_t* dy, const bf16_t* dx_in, bf16_t* dx, int N, int H, int W, int C,
                                      int Ho, int Wo) {
   const int C8 = C >> 3;
@@ -283,7 +289,7 @@ __global__ void subsample_bwd_kernel(const bf16_t* dy, const bf16_t* dx_in, bf16
     if (dx_in) {
       const bf16x8_t v = *(const bf16x8_t*)(dx_in + i * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = (float)v[e];
+      for (int e = 0; e < 8; ++e) acc[e] = elem_to_f32<F16>(v[e]);
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -291,61 +297,62 @@ __global__ void subsample_bwd_kernel(const bf16_t* dy, const bf16_t* dx_in, bf16
     if (((h | w) & 1) == 0) {
       const bf16x8_t g = *(const bf16x8_t*)(dy + ((((int64_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C8 + c8) * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (float)g[e];
+      for (int e = 0; e < 8; ++e) acc[e] += elem_to_f32<F16>(g[e]);
     }
     bf16x8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
+    for (int e = 0; e < 8; ++e) o[e] = f32_to_elem<F16>(acc[e]);
     *(bf16x8_t*)(dx + i * 8) = o;
   }
 }
 
 extern "C" int tdn_subsample2_bwd(const void* dy, const void* dx_in, void* dx, int N, int H, int W, int C, int dtype,
                                   void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "tdn_subsample2_bwd: bad arguments");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  hipLaunchKernelGGL(subsample_bwd_kernel, dim3(grid_for((int64_t)N * H * W * (C / 8), 256)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dx_in, (bf16_t*)dx, N, H, W, C, Ho, Wo);
+  TDN_LAUNCH_T(subsample_bwd_kernel, dtype, dim3(grid_for((int64_t)N * H * W * (C / 8), 256)), dim3(256), (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)dx_in, (bf16_t*)dx, N, H, W, C, Ho, Wo);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
 // ---- out = (a + b) masked by mask > 0 ---------------------------------------------------------------
+template <bool F16>
 __global__ void add_relu_mask_kernel(const bf16_t* a, const bf16_t* b, const bf16_t* mask, bf16_t* out, int64_t n8) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
     const bf16x8_t va = *(const bf16x8_t*)(a + i * 8);
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (float)va[e];
+    for (int e = 0; e < 8; ++e) v[e] = elem_to_f32<F16>(va[e]);
     if (b) {
       const bf16x8_t vb = *(const bf16x8_t*)(b + i * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += (float)vb[e];
+      for (int e = 0; e < 8; ++e) v[e] += elem_to_f32<F16>(vb[e]);
     }
     if (mask) {
       const bf16x8_t mk = *(const bf16x8_t*)(mask + i * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ((float)mk[e] > 0.f) ? v[e] : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = (elem_to_f32<F16>(mk[e]) > 0.f) ? v[e] : 0.f;
     }
     bf16x8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    for (int e = 0; e < 8; ++e) o[e] = f32_to_elem<F16>(v[e]);
     *(bf16x8_t*)(out + i * 8) = o;
   }
 }
 
 extern "C" int tdn_add_relu_mask(const void* a, const void* b, const void* mask_src, void* out, int64_t n, int dtype,
                                  void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(a && out && n > 0 && n % 8 == 0, "tdn_add_relu_mask: bad arguments (n=%lld)", (long long)n);
-  hipLaunchKernelGGL(add_relu_mask_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+  TDN_LAUNCH_T(add_relu_mask_kernel, dtype, dim3(grid_for(n / 8, 256)), dim3(256), (hipStream_t)stream,
                      (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)mask_src, (bf16_t*)out, n / 8);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
 // ---- boundary layout converters -----------------------------------------------------------------------
+template <bool F16>
 __global__ void nchw_to_nhwc_kernel(const float* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N,
                                     int C, int H, int W, bf16_t* dst) {
   // tile transpose through LDS: 32 pixels x 32 channels per block step
@@ -371,7 +378,7 @@ __global__ void nchw_to_nhwc_kernel(const float* src, int64_t s_n, int64_t s_c, 
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
       const int pix = tp * 32 + k, c = tc * 32 + tx;
-      if (c < C && pix < HW) dst[((int64_t)n * HW + pix) * C + c] = (bf16_t)t[tx][k];
+      if (c < C && pix < HW) dst[((int64_t)n * HW + pix) * C + c] = f32_to_elem<F16>(t[tx][k]);
     }
     __syncthreads();
   }
@@ -379,15 +386,15 @@ __global__ void nchw_to_nhwc_kernel(const float* src, int64_t s_n, int64_t s_c, 
 
 extern "C" int tdn_nchw_f32_to_nhwc(const float* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N,
                                     int C, int H, int W, void* dst, int dtype, void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "tdn_nchw_f32_to_nhwc: bad arguments");
   const int64_t ntiles = (int64_t)N * ceil_div(H * W, 32) * ceil_div(C, 32);
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((int)(ntiles < 8192 ? ntiles : 8192)), dim3(256), 0,
-                     (hipStream_t)stream, src, s_n, s_c, s_h, s_w, N, C, H, W, (bf16_t*)dst);
+  TDN_LAUNCH_T(nchw_to_nhwc_kernel, dtype, dim3((int)(ntiles < 8192 ? ntiles : 8192)), dim3(256), (hipStream_t)stream, src, s_n, s_c, s_h, s_w, N, C, H, W, (bf16_t*)dst);
   TDN_LAUNCH_CHECK();
   return 0;
 }
 
+template <bool F16>
 __global__ void nhwc_to_nchw_kernel(const bf16_t* src, int N, int C, int H, int W, float* dst) {
   __shared__ float t[32][33];
   const int HW = H * W;
@@ -401,7 +408,7 @@ __global__ void nhwc_to_nchw_kernel(const bf16_t* src, int N, int C, int H, int 
     const int n = (int)(r / tiles_p);
     for (int k = ty; k < 32; k += 8) {
       const int pix = tp * 32 + k, c = tc * 32 + tx;
-      t[k][tx] = (c < C && pix < HW) ? (float)src[((int64_t)n * HW + pix) * C + c] : 0.f;
+      t[k][tx] = (c < C && pix < HW) ? elem_to_f32<F16>(src[((int64_t)n * HW + pix) * C + c]) : 0.f;
     }
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
@@ -414,11 +421,10 @@ __global__ void nhwc_to_nchw_kernel(const bf16_t* src, int N, int C, int H, int 
 
 extern "C" int tdn_nhwc_to_nchw_f32(const void* src, int N, int C, int H, int W, float* dst, int dtype,
                                     void* stream) {
-  TDN_CHECK(dtype == TDN_BF16, "only TDN_BF16 is supported");
+  TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "tdn_nhwc_to_nchw_f32: bad arguments");
   const int64_t ntiles = (int64_t)N * ceil_div(H * W, 32) * ceil_div(C, 32);
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((int)(ntiles < 8192 ? ntiles : 8192)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)src, N, C, H, W, dst);
+  TDN_LAUNCH_T(nhwc_to_nchw_kernel, dtype, dim3((int)(ntiles < 8192 ? ntiles : 8192)), dim3(256), (hipStream_t)stream, (const bf16_t*)src, N, C, H, W, dst);
   TDN_LAUNCH_CHECK();
   return 0;
 }

@@ -102,7 +102,7 @@ class GradReducer(object):
         self.reset()
 
 
-def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True):
+def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True, dtype=None):
     """Wire ``GradReducer`` into HIP-path modules (given in the order their backward runs, e.g. [fpn, resnet]).
 
     Every conv unit's weight/affine gradients get a slot in the flat buffer (in backward-completion order),
@@ -111,7 +111,7 @@ def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True):
     """
     units = []
     for m in modules:
-        net = m.hip_net()
+        net = m.hip_net(dtype)   # the units of the compute dtype the forward will use (default: compute_dtype)
         us = net.units()
         # FPN finishes fpn_convs then laterals; SeqNet finishes last block first, stem last
         order = list(us) if hasattr(net, 'lat') else list(reversed(us))

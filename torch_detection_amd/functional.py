@@ -33,7 +33,9 @@ DEBUG_CAPTURE = None
 class ConvUnit(object):
     """One conv (+BN | +bias) of the reference, prepared for the GEMM kernels."""
 
-    def __init__(self, conv, bn, relu=False):
+    def __init__(self, conv, bn, relu=False, dtype=torch.bfloat16):
+        ops.dtype_code(dtype)   # validates
+        self.dtype = dtype      # element type of the packed operands = compute dtype of every launch using them
         if not isinstance(conv, nn.Conv2d):
             raise TypeError('expected nn.Conv2d, got %s' % type(conv))
         kh, kw = conv.kernel_size
@@ -75,7 +77,7 @@ class ConvUnit(object):
 
     def _version_key(self):
         w = self.conv.weight
-        key = [w.data_ptr(), w._version, w.device]
+        key = [w.data_ptr(), w._version, w.device, self.dtype]
         if self.bn is not None:
             for t in (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var):
                 key += [t.data_ptr(), t._version]
@@ -108,21 +110,31 @@ class ConvUnit(object):
                 self.scale = self.invstd = self.mean = None
                 self.shift = self.conv.bias.detach() if self.conv.bias is not None else None
             if self.is_stem:
-                self.w_fwd = ops.pack_stem_weight(w.detach().contiguous())
+                self.w_fwd = ops.pack_stem_weight(w.detach().contiguous(), self.dtype)
                 self.w_dgrad = None
             else:
-                self.w_fwd, self.w_dgrad = ops.pack_conv_weight(w, self.scale)
+                self.w_fwd, self.w_dgrad = ops.pack_conv_weight(w, self.scale, True, self.dtype)
         self.key = key
         return self
 
 
-def prepare_unit(owner, name, conv, bn, relu=False):
-    """Cached ConvUnit stored on ``owner`` (a module) under ``name``; refreshed if parameters changed."""
+def pick_dtype(module, x):
+    """Compute dtype of a forward call: the input's own 16-bit float dtype when it has one (fp16 in -> fp16 compute,
+    like ``model.half()(x.half())`` on the reference), else the module's ``compute_dtype`` attribute (default
+    bfloat16).  Parameters stay float32 master copies either way."""
+    t = x[0] if isinstance(x, (tuple, list)) else x
+    if t.dtype in (torch.float16, torch.bfloat16):
+        return t.dtype
+    return getattr(module, 'compute_dtype', torch.bfloat16)
+
+
+def prepare_unit(owner, name, conv, bn, relu=False, dtype=torch.bfloat16):
+    """Cached ConvUnit stored on ``owner`` (a module) under ``(name, dtype)``; refreshed if parameters changed."""
     cache = owner.__dict__.setdefault('_hip_units', {})
-    u = cache.get(name)
+    u = cache.get((name, dtype))
     if u is None or u.conv is not conv or u.bn is not bn:
-        u = ConvUnit(conv, bn, relu)
-        cache[name] = u
+        u = ConvUnit(conv, bn, relu, dtype)
+        cache[(name, dtype)] = u
     u.relu = relu
     return u.refresh()
 
@@ -243,7 +255,7 @@ class ConvUnitFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, unit, x, *params):
-        xh = ops.to_nhwc_bf16(x)
+        xh = ops.to_nhwc_bf16(x, unit.dtype)
         y = unit_fwd(unit, xh)
         ctx.unit, ctx.xh, ctx.y = unit, xh, y
         return _as_nchw(y)
@@ -251,7 +263,7 @@ class ConvUnitFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         u = ctx.unit
-        g = ops.to_nhwc_bf16(dy)
+        g = ops.to_nhwc_bf16(dy, u.dtype)
         if u.relu:
             g = ops.add_relu_mask(g, None, ctx.y)
         grads = unit_wgrad(u, ctx.xh, g)
@@ -278,6 +290,7 @@ class SeqNet(object):
 
     def __init__(self, stem, blocks, out_blocks):
         self.stem, self.blocks, self.out_blocks = stem, blocks, list(out_blocks)
+        self.dtype = (stem or blocks[0].u1).dtype
 
     def units(self):
         us = [self.stem] if self.stem is not None else []
@@ -346,12 +359,12 @@ class SeqNetFunction(torch.autograd.Function):
                 raise RuntimeError('ResNet expects an (N,3,H,W) image batch, got %s' % (tuple(x.shape),))
             img = x if x.dtype == torch.float32 else x.float()
             H, W = img.shape[2], img.shape[3]
-            xp = ops.stage_image(img)
+            xp = ops.stage_image(img, net.dtype)
             s = ops.stem_conv_fwd(xp, net.stem.w_fwd, (H, W), net.stem.scale, net.stem.shift, True)
             cur, idx = ops.maxpool3x3s2_fwd(s)
             st.update(xp=xp, s=s, idx=idx, img_hw=(H, W))
         else:
-            cur = ops.to_nhwc_bf16(x)
+            cur = ops.to_nhwc_bf16(x, net.dtype)
         saved, outs = [], []
         for bi, b in enumerate(net.blocks):
             cur, sv = _block_fwd(cur, b)
@@ -371,7 +384,7 @@ class SeqNetFunction(torch.autograd.Function):
         ext = {}
         for bi, d in zip(net.out_blocks, douts):
             if d is not None:
-                ext[bi] = ops.to_nhwc_bf16(d)
+                ext[bi] = ops.to_nhwc_bf16(d, net.dtype)
         unit_grads = {}
         need_net_dx = ctx.needs_input_grad[1] and net.stem is None
         g = None
@@ -411,6 +424,7 @@ class FPNNet(object):
         self.lat, self.fpn = lat, fpn
         self.start_level, self.backbone_end_level = start_level, backbone_end_level
         self.num_outs, self.add_extra_convs, self.num_ins = num_outs, add_extra_convs, num_ins
+        self.dtype = lat[0].dtype
 
     def units(self):
         return list(self.lat) + list(self.fpn)
@@ -430,7 +444,7 @@ class FPNFunction(torch.autograd.Function):
     def forward(ctx, net, *args):
         inputs = args[:net.num_ins]
         nlat = len(net.lat)
-        xs = [ops.to_nhwc_bf16(inputs[i + net.start_level]) for i in range(nlat)]
+        xs = [ops.to_nhwc_bf16(inputs[i + net.start_level], net.dtype) for i in range(nlat)]
         lat = [None] * nlat
         for i in reversed(range(nlat)):
             if i == nlat - 1:
@@ -444,7 +458,7 @@ class FPNFunction(torch.autograd.Function):
                 for _ in range(net.num_outs - nlat):
                     outs.append(ops.subsample2_fwd(outs[-1]))
             else:
-                orig = ops.to_nhwc_bf16(inputs[net.backbone_end_level - 1])
+                orig = ops.to_nhwc_bf16(inputs[net.backbone_end_level - 1], net.dtype)
                 outs.append(unit_fwd(net.fpn[nlat], orig))
                 extra_in.append(orig)
                 for i in range(nlat + 1, net.num_outs):
@@ -464,11 +478,11 @@ class FPNFunction(torch.autograd.Function):
         net, xs, lat = ctx.net, ctx.xs, ctx.lat
         nlat = len(net.lat)
         N, C, dev = ctx.out_meta
-        d = [ops.to_nhwc_bf16(t) if t is not None else None for t in douts]
+        d = [ops.to_nhwc_bf16(t, net.dtype) if t is not None else None for t in douts]
 
         def zeros(i):
             h, w = ctx.out_hw[i]
-            return torch.zeros(N, h, w, C, dtype=ops.BF16, device=dev)
+            return torch.zeros(N, h, w, C, dtype=net.dtype, device=dev)
 
         unit_grads = {}
         dx = [None] * net.num_ins
@@ -513,6 +527,7 @@ class FPNFunction(torch.autograd.Function):
 class PAPathNet(object):
     def __init__(self, pa1, pa2, num_extra):
         self.pa1, self.pa2, self.num_extra = pa1, pa2, num_extra
+        self.dtype = pa1[0].dtype
 
     def units(self):
         us = []
@@ -535,7 +550,7 @@ class PAPathFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, *args):
         n = len(net.pa1) + 1
-        P = [ops.to_nhwc_bf16(t) for t in args[:n]]
+        P = [ops.to_nhwc_bf16(t, net.dtype) for t in args[:n]]
         outs, t_saved, s_saved = [P[0]], [], []
         for i in range(1, n):
             u1, u2 = net.pa1[i - 1], net.pa2[i - 1]
@@ -557,7 +572,7 @@ class PAPathFunction(torch.autograd.Function):
     def backward(ctx, *douts):
         net, outs, n = ctx.net, ctx.outs, ctx.n
         dev = outs[0].device
-        d = [ops.to_nhwc_bf16(t) if t is not None else None for t in douts]
+        d = [ops.to_nhwc_bf16(t, net.dtype) if t is not None else None for t in douts]
         for j in range(len(outs) - 1, n - 1, -1):       # fold the subsampled extra levels back
             if d[j] is not None:
                 d[j - 1] = ops.subsample2_bwd(d[j], _hw(outs[j - 1]), d[j - 1])

@@ -100,7 +100,7 @@ class ConvModule(nn.Module):
             elif self.activation == 'relu6':
                 self.activate = nn.ReLU6(inplace=True)
 
-    def hip_unit(self):
+    def hip_unit(self, dtype=torch.bfloat16):
         """Prepared (cached) fused-conv unit of this module; raises for configurations not on the HIP path."""
         if not self.activate_last:
             raise NotImplementedError('ConvModule(activate_last=False) is not on the HIP path yet')
@@ -109,8 +109,8 @@ class ConvModule(nn.Module):
         if self.with_activation and self.activation != 'relu':
             raise NotImplementedError("ConvModule activation %r is not on the HIP path yet" % self.activation)
         return HF.prepare_unit(self, 'conv', self.conv, self.norm if self.with_norm else None,
-                               relu=self.with_activation)
+                               self.with_activation, dtype)
 
     def forward(self, x):
-        unit = self.hip_unit()
+        unit = self.hip_unit(HF.pick_dtype(self, x))
         return HF.ConvUnitFunction.apply(unit, x, *unit.params())

@@ -8,6 +8,7 @@ lateral 1x1 conv's epilogue and its adjoint (2x2 sum-pool) into the 3x3 dgrad ep
 As in the reference, every level must be exactly 2x the next one, otherwise RuntimeError (fpn.py:100 raises
 the same type): inputs must come from a batch padded to a multiple of 32 (datasets/utils/image.py:326-347).
 """
+import torch
 import torch.nn as nn
 
 from .. import functional as HF
@@ -63,13 +64,15 @@ class FPN(nn.Module):
             if isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
                 constant_init(m, 1)
 
-    def hip_net(self):
-        lat = [m.hip_unit() for m in self.lateral_convs]
-        fpn = [m.hip_unit() for m in self.fpn_convs]
+    def hip_net(self, dtype=None):
+        if dtype is None:
+            dtype = getattr(self, 'compute_dtype', torch.bfloat16)
+        lat = [m.hip_unit(dtype) for m in self.lateral_convs]
+        fpn = [m.hip_unit(dtype) for m in self.fpn_convs]
         return HF.FPNNet(lat, fpn, self.start_level, self.backbone_end_level, self.num_outs,
                          self.add_extra_convs, self.num_ins)
 
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        net = self.hip_net()
+        net = self.hip_net(HF.pick_dtype(self, inputs))
         return HF.FPNFunction.apply(net, *(tuple(inputs) + tuple(net.params())))

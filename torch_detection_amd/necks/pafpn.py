@@ -70,10 +70,11 @@ class PAFPN(nn.Module):
             raise NotImplementedError('PAFPN(add_extra_convs=True) extra stride-2 conv levels are not on the HIP '
                                       'path yet')
         nlat = len(self.lateral_convs)
-        lat = [m.hip_unit() for m in self.lateral_convs]
-        fpn = [m.hip_unit() for m in self.fpn_convs[:nlat]]
+        dtype = HF.pick_dtype(self, inputs)
+        lat = [m.hip_unit(dtype) for m in self.lateral_convs]
+        fpn = [m.hip_unit(dtype) for m in self.fpn_convs[:nlat]]
         fnet = HF.FPNNet(lat, fpn, self.start_level, self.backbone_end_level, nlat, False, self.num_ins)
         P = HF.FPNFunction.apply(fnet, *(tuple(inputs) + tuple(fnet.params())))
-        pnet = HF.PAPathNet([m.hip_unit() for m in self.pa_convs1], [m.hip_unit() for m in self.pa_convs2],
+        pnet = HF.PAPathNet([m.hip_unit(dtype) for m in self.pa_convs1], [m.hip_unit(dtype) for m in self.pa_convs2],
                             self.num_outs - nlat)
         return HF.PAPathFunction.apply(pnet, *(tuple(P) + tuple(pnet.params())))

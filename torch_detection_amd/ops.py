@@ -1,6 +1,7 @@
 """Host-side operator layer: torch tensors in, C-ABI calls out (libtdn.so, include/tdn.h).
 
-Activations are NHWC bfloat16 tensors of shape (N, H, W, C), contiguous.  Every function validates
+Activations are NHWC bfloat16 (default) or float16 tensors of shape (N, H, W, C), contiguous; the element type of
+a call is the one of its activation operand and every other 16-bit operand must match it.  Every function validates
 shapes on the host before launching (a mis-shaped launch can fault the GPU), enqueues on PyTorch's
 current HIP stream, and never synchronises.  There is no non-HIP fallback.
 """
@@ -9,19 +10,31 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ADD_NONE, ADD_SAME, ADD_SUMPOOL2, ADD_UP2X, TDN_BF16, Epilogue  # noqa: F401
+from ._lib import ADD_NONE, ADD_SAME, ADD_SUMPOOL2, ADD_UP2X, TDN_BF16, TDN_F16, Epilogue  # noqa: F401
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+_CODES = {BF16: TDN_BF16, F16: TDN_F16}
+
+
+def dtype_code(dtype):
+    """tdn dtype code (include/tdn.h) of a torch 16-bit float dtype."""
+    try:
+        return _CODES[dtype]
+    except KeyError:
+        raise ValueError("compute dtype must be torch.bfloat16 or torch.float16, got %s" % (dtype,))
 
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _chk_act(t, name, C=None):
-    if t.dtype != BF16 or not t.is_cuda or t.dim() != 4 or not t.is_contiguous():
-        raise ValueError("%s must be a contiguous CUDA bfloat16 NHWC tensor, got %s %s %s" %
+def _chk_act(t, name, C=None, dtype=None):
+    if t.dtype not in _CODES or not t.is_cuda or t.dim() != 4 or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous CUDA bfloat16/float16 NHWC tensor, got %s %s %s" %
                          (name, t.dtype, t.device, tuple(t.shape)))
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError("%s is %s but the call computes in %s" % (name, t.dtype, dtype))
     if C is not None and t.shape[3] != C:
         raise ValueError("%s: expected %d channels, got %d" % (name, C, t.shape[3]))
 
@@ -38,7 +51,7 @@ def conv_out_size(h, k, stride, pad):
 
 
 def make_epilogue(Cout, Ho, Wo, scale=None, shift=None, addend=None, addend_mode=ADD_NONE, relu=False,
-                  mask_src=None, N=None, out_f32=False):
+                  mask_src=None, N=None, out_f32=False, dtype=None):
     _chk_vec(scale, "scale", Cout)
     _chk_vec(shift, "shift", Cout)
     ep = Epilogue()
@@ -48,7 +61,7 @@ def make_epilogue(Cout, Ho, Wo, scale=None, shift=None, addend=None, addend_mode
     ep.out_f32 = 1 if out_f32 else 0
     ep.addend_mode = ADD_NONE
     if addend is not None and addend_mode != ADD_NONE:
-        _chk_act(addend, "addend", Cout)
+        _chk_act(addend, "addend", Cout, dtype)
         exp = {ADD_SAME: (Ho, Wo), ADD_UP2X: (Ho // 2, Wo // 2), ADD_SUMPOOL2: (Ho * 2, Wo * 2)}[addend_mode]
         if tuple(addend.shape[1:3]) != exp or (addend_mode == ADD_UP2X and (Ho % 2 or Wo % 2)) or \
                 (N is not None and addend.shape[0] != N):
@@ -58,7 +71,7 @@ def make_epilogue(Cout, Ho, Wo, scale=None, shift=None, addend=None, addend_mode
         ep.addend_mode = addend_mode
         ep.addend_h, ep.addend_w = addend.shape[1], addend.shape[2]
     if mask_src is not None:
-        _chk_act(mask_src, "mask_src", Cout)
+        _chk_act(mask_src, "mask_src", Cout, dtype)
         if tuple(mask_src.shape[1:3]) != (Ho, Wo) or (N is not None and mask_src.shape[0] != N):
             raise RuntimeError("mask_src shape %s does not match output" % (tuple(mask_src.shape),))
         ep.mask_src = mask_src.data_ptr()
@@ -76,29 +89,29 @@ def bn_fold(gamma, beta, mean, var, eps):
     return out[0], out[1], out[2]
 
 
-def pack_conv_weight(w, scale=None, want_dgrad=True):
-    """fp32 OIHW (any strides) -> (w_fwd bf16 [O][kh][kw][I], w_dgrad bf16 [I][kh][kw][O] with scale folded)."""
+def pack_conv_weight(w, scale=None, want_dgrad=True, dtype=BF16):
+    """fp32 OIHW (any strides) -> (w_fwd [O][kh][kw][I], w_dgrad [I][kh][kw][O] with scale folded), both `dtype`."""
     w = w.detach()
     if w.dtype != torch.float32 or not w.is_cuda or w.dim() != 4:
         raise ValueError("weight must be a CUDA float32 4-D tensor")
     O, I, kh, kw = w.shape
     _chk_vec(scale, "scale", O)
-    w_fwd = torch.empty(O, kh, kw, I, dtype=BF16, device=w.device)
-    w_dg = torch.empty(I, kh, kw, O, dtype=BF16, device=w.device) if want_dgrad else None
+    w_fwd = torch.empty(O, kh, kw, I, dtype=dtype, device=w.device)
+    w_dg = torch.empty(I, kh, kw, O, dtype=dtype, device=w.device) if want_dgrad else None
     s = w.stride()
     _lib.check(_lib.load().tdn_pack_conv_weight(_ptr(w), s[0], s[1], s[2], s[3], O, I, kh, kw, _ptr(scale),
-                                                _ptr(w_fwd), _ptr(w_dg), TDN_BF16, _lib.stream_ptr()),
+                                                _ptr(w_fwd), _ptr(w_dg), dtype_code(dtype), _lib.stream_ptr()),
                "tdn_pack_conv_weight")
     return w_fwd, w_dg
 
 
-def pack_stem_weight(w):
+def pack_stem_weight(w, dtype=BF16):
     w = w.detach()
     if w.dtype != torch.float32 or not w.is_cuda or tuple(w.shape[1:]) != (3, 7, 7) or not w.is_contiguous():
         raise ValueError("stem weight must be a contiguous CUDA float32 [Cout,3,7,7] tensor")
     O = w.shape[0]
-    out = torch.empty(O, 7, 8, 4, dtype=BF16, device=w.device)
-    _lib.check(_lib.load().tdn_pack_stem_weight(_ptr(w), O, _ptr(out), TDN_BF16, _lib.stream_ptr()),
+    out = torch.empty(O, 7, 8, 4, dtype=dtype, device=w.device)
+    _lib.check(_lib.load().tdn_pack_stem_weight(_ptr(w), O, _ptr(out), dtype_code(dtype), _lib.stream_ptr()),
                "tdn_pack_stem_weight")
     return out
 
@@ -108,13 +121,14 @@ def conv2d_fwd(x, w_fwd, k, stride, pad, scale=None, shift=None, addend=None, ad
     _chk_act(x, "x")
     N, H, W, Cin = x.shape
     Cout = w_fwd.shape[0]
-    if w_fwd.dtype != BF16 or tuple(w_fwd.shape) != (Cout, k, k, Cin) or not w_fwd.is_contiguous():
-        raise ValueError("w_fwd must be bf16 [Cout,k,k,Cin] contiguous, got %s" % (tuple(w_fwd.shape),))
+    if w_fwd.dtype != x.dtype or tuple(w_fwd.shape) != (Cout, k, k, Cin) or not w_fwd.is_contiguous():
+        raise ValueError("w_fwd must be %s [Cout,k,k,Cin] contiguous, got %s %s" %
+                         (x.dtype, w_fwd.dtype, tuple(w_fwd.shape)))
     Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
-    y = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32 if out_f32 else BF16, device=x.device)
-    ep = make_epilogue(Cout, Ho, Wo, scale, shift, addend, addend_mode, relu, None, N, out_f32)
+    y = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    ep = make_epilogue(Cout, Ho, Wo, scale, shift, addend, addend_mode, relu, None, N, out_f32, x.dtype)
     _lib.check(_lib.load().tdn_conv2d_fwd(_ptr(x), _ptr(w_fwd), _ptr(y), N, H, W, Cin, Cout, k, stride, pad,
-                                          ctypes.byref(ep), TDN_BF16, _lib.stream_ptr()), "tdn_conv2d_fwd")
+                                          ctypes.byref(ep), dtype_code(x.dtype), _lib.stream_ptr()), "tdn_conv2d_fwd")
     return y
 
 
@@ -125,14 +139,15 @@ def conv2d_dgrad(g, w_dgrad, in_hw, k, stride, pad, addend=None, addend_mode=ADD
     N, Ho, Wo, Cout = g.shape
     H, W = in_hw
     Cin = w_dgrad.shape[0]
-    if w_dgrad.dtype != BF16 or tuple(w_dgrad.shape) != (Cin, k, k, Cout) or not w_dgrad.is_contiguous():
-        raise ValueError("w_dgrad must be bf16 [Cin,k,k,Cout] contiguous, got %s" % (tuple(w_dgrad.shape),))
+    if w_dgrad.dtype != g.dtype or tuple(w_dgrad.shape) != (Cin, k, k, Cout) or not w_dgrad.is_contiguous():
+        raise ValueError("w_dgrad must be %s [Cin,k,k,Cout] contiguous, got %s %s" %
+                         (g.dtype, w_dgrad.dtype, tuple(w_dgrad.shape)))
     if (Ho, Wo) != (conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)):
         raise RuntimeError("dgrad: g spatial size %s inconsistent with input %s" % ((Ho, Wo), (H, W)))
-    dx = torch.empty(N, H, W, Cin, dtype=torch.float32 if out_f32 else BF16, device=g.device)
-    ep = make_epilogue(Cin, H, W, None, None, addend, addend_mode, False, mask_src, N, out_f32)
+    dx = torch.empty(N, H, W, Cin, dtype=torch.float32 if out_f32 else g.dtype, device=g.device)
+    ep = make_epilogue(Cin, H, W, None, None, addend, addend_mode, False, mask_src, N, out_f32, g.dtype)
     _lib.check(_lib.load().tdn_conv2d_dgrad(_ptr(g), _ptr(w_dgrad), _ptr(dx), N, H, W, Cin, Cout, k, stride, pad,
-                                            ctypes.byref(ep), TDN_BF16, _lib.stream_ptr()), "tdn_conv2d_dgrad")
+                                            ctypes.byref(ep), dtype_code(g.dtype), _lib.stream_ptr()), "tdn_conv2d_dgrad")
     return dx
 
 
@@ -153,7 +168,9 @@ def conv2d_wgrad(x, g, w_fwd, k, stride, pad, scale=None, mean=None, invstd=None
                  dbeta=None, beta=0.0):
     """Weight + affine grads. dw: fp32 [Cout,k,k,Cin] (written, or accumulated when beta=1)."""
     _chk_act(x, "x")
-    _chk_act(g, "g")
+    _chk_act(g, "g", None, x.dtype)
+    if w_fwd.dtype != x.dtype:
+        raise ValueError("wgrad: w_fwd is %s but activations are %s" % (w_fwd.dtype, x.dtype))
     N, H, W, Cin = x.shape
     Cout = g.shape[3]
     Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
@@ -176,19 +193,19 @@ def conv2d_wgrad(x, g, w_fwd, k, stride, pad, scale=None, mean=None, invstd=None
     ws = _workspace(nbytes, dev)
     _lib.check(lib.tdn_conv2d_wgrad(_ptr(x), _ptr(g), _ptr(w_fwd), _ptr(scale), _ptr(mean), _ptr(invstd), _ptr(dw),
                                     _ptr(dgamma), _ptr(dbeta), float(beta), N, H, W, Cin, Cout, k, stride, pad,
-                                    _ptr(ws), ws.numel(), TDN_BF16, _lib.stream_ptr()), "tdn_conv2d_wgrad")
+                                    _ptr(ws), ws.numel(), dtype_code(x.dtype), _lib.stream_ptr()), "tdn_conv2d_wgrad")
     return dw, dgamma, dbeta
 
 
-def stage_image(img):
-    """NCHW float32 image batch (any strides) -> zero-padded NHWC4 bf16 (N, H+6, W+8, 4)."""
+def stage_image(img, dtype=BF16):
+    """NCHW float32 image batch (any strides) -> zero-padded NHWC4 `dtype` (N, H+6, W+8, 4)."""
     if img.dtype != torch.float32 or not img.is_cuda or img.dim() != 4 or img.shape[1] != 3:
         raise ValueError("image batch must be CUDA float32 (N,3,H,W), got %s %s" % (img.dtype, tuple(img.shape)))
     N, _, H, W = img.shape
-    xp = torch.empty(N, H + 6, W + 8, 4, dtype=BF16, device=img.device)
+    xp = torch.empty(N, H + 6, W + 8, 4, dtype=dtype, device=img.device)
     s = img.stride()
-    _lib.check(_lib.load().tdn_stage_image(_ptr(img), s[0], s[1], s[2], s[3], N, H, W, _ptr(xp), TDN_BF16,
-                                           _lib.stream_ptr()), "tdn_stage_image")
+    _lib.check(_lib.load().tdn_stage_image(_ptr(img), s[0], s[1], s[2], s[3], N, H, W, _ptr(xp),
+                                           dtype_code(dtype), _lib.stream_ptr()), "tdn_stage_image")
     return xp
 
 
@@ -196,17 +213,17 @@ def stem_conv_fwd(xp, w_stem, hw, scale=None, shift=None, relu=True, out_f32=Fal
     H, W = hw
     N = xp.shape[0]
     Cout = w_stem.shape[0]
-    if tuple(xp.shape) != (N, H + 6, W + 8, 4) or xp.dtype != BF16 or not xp.is_contiguous():
-        raise ValueError("xp must be the staged image (N,H+6,W+8,4) bf16")
-    if tuple(w_stem.shape) != (Cout, 7, 8, 4) or w_stem.dtype != BF16:
-        raise ValueError("w_stem must be bf16 [Cout,7,8,4]")
+    if tuple(xp.shape) != (N, H + 6, W + 8, 4) or xp.dtype not in _CODES or not xp.is_contiguous():
+        raise ValueError("xp must be the staged image (N,H+6,W+8,4) in bf16/fp16")
+    if tuple(w_stem.shape) != (Cout, 7, 8, 4) or w_stem.dtype != xp.dtype:
+        raise ValueError("w_stem must be %s [Cout,7,8,4]" % (xp.dtype,))
     if H % 2 or W % 2:
         raise RuntimeError("stem conv needs even H and W (got %dx%d); pad the batch as the reference pipeline does "
                            "(size_divisor, datasets/utils/image.py:326-347)" % (H, W))
-    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32 if out_f32 else BF16, device=xp.device)
+    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32 if out_f32 else xp.dtype, device=xp.device)
     ep = make_epilogue(Cout, H // 2, W // 2, scale, shift, None, ADD_NONE, relu, None, N, out_f32)
     _lib.check(_lib.load().tdn_stem_conv_fwd(_ptr(xp), _ptr(w_stem), _ptr(y), N, H, W, Cout, ctypes.byref(ep),
-                                             TDN_BF16, _lib.stream_ptr()), "tdn_stem_conv_fwd")
+                                             dtype_code(xp.dtype), _lib.stream_ptr()), "tdn_stem_conv_fwd")
     return y
 
 
@@ -215,7 +232,9 @@ def stem_conv_wgrad(xp, g, w_stem, hw, scale=None, mean=None, invstd=None, dw=No
     H, W = hw
     N = xp.shape[0]
     Cout = w_stem.shape[0]
-    _chk_act(g, "g", Cout)
+    _chk_act(g, "g", Cout, xp.dtype)
+    if w_stem.dtype != xp.dtype:
+        raise ValueError("stem wgrad: w_stem is %s but the staged image is %s" % (w_stem.dtype, xp.dtype))
     if tuple(g.shape) != (N, H // 2, W // 2, Cout) or tuple(xp.shape) != (N, H + 6, W + 8, 4):
         raise RuntimeError("stem wgrad: inconsistent shapes")
     dev = g.device
@@ -232,7 +251,7 @@ def stem_conv_wgrad(xp, g, w_stem, hw, scale=None, mean=None, invstd=None, dw=No
     ws = _workspace(nbytes, dev)
     _lib.check(lib.tdn_stem_conv_wgrad(_ptr(xp), _ptr(g), _ptr(w_stem), _ptr(scale), _ptr(mean), _ptr(invstd),
                                        _ptr(dw), _ptr(dgamma), _ptr(dbeta), float(beta), N, H, W, Cout, _ptr(ws),
-                                       ws.numel(), TDN_BF16, _lib.stream_ptr()), "tdn_stem_conv_wgrad")
+                                       ws.numel(), dtype_code(xp.dtype), _lib.stream_ptr()), "tdn_stem_conv_wgrad")
     return dw, dgamma, dbeta
 
 
@@ -240,9 +259,9 @@ def maxpool3x3s2_fwd(x):
     _chk_act(x, "x")
     N, H, W, C = x.shape
     Ho, Wo = conv_out_size(H, 3, 2, 1), conv_out_size(W, 3, 2, 1)
-    y = torch.empty(N, Ho, Wo, C, dtype=BF16, device=x.device)
+    y = torch.empty(N, Ho, Wo, C, dtype=x.dtype, device=x.device)
     idx = torch.empty(N, Ho, Wo, C, dtype=torch.uint8, device=x.device)
-    _lib.check(_lib.load().tdn_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(idx), N, H, W, C, TDN_BF16,
+    _lib.check(_lib.load().tdn_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(idx), N, H, W, C, dtype_code(x.dtype),
                                                 _lib.stream_ptr()), "tdn_maxpool3x3s2_fwd")
     return y, idx
 
@@ -254,20 +273,20 @@ def maxpool3x3s2_bwd(dy, idx, in_hw, mask_src=None):
     if (Ho, Wo) != (conv_out_size(H, 3, 2, 1), conv_out_size(W, 3, 2, 1)) or tuple(idx.shape) != tuple(dy.shape):
         raise RuntimeError("maxpool bwd: inconsistent shapes")
     if mask_src is not None:
-        _chk_act(mask_src, "mask_src", C)
+        _chk_act(mask_src, "mask_src", C, dy.dtype)
         if tuple(mask_src.shape) != (N, H, W, C):
             raise RuntimeError("maxpool bwd: mask_src shape mismatch")
-    dx = torch.empty(N, H, W, C, dtype=BF16, device=dy.device)
-    _lib.check(_lib.load().tdn_maxpool3x3s2_bwd(_ptr(dy), _ptr(idx), _ptr(mask_src), _ptr(dx), N, H, W, C, TDN_BF16,
-                                                _lib.stream_ptr()), "tdn_maxpool3x3s2_bwd")
+    dx = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().tdn_maxpool3x3s2_bwd(_ptr(dy), _ptr(idx), _ptr(mask_src), _ptr(dx), N, H, W, C,
+                                                dtype_code(dy.dtype), _lib.stream_ptr()), "tdn_maxpool3x3s2_bwd")
     return dx
 
 
 def subsample2_fwd(x):
     _chk_act(x, "x")
     N, H, W, C = x.shape
-    y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, C, dtype=BF16, device=x.device)
-    _lib.check(_lib.load().tdn_subsample2_fwd(_ptr(x), _ptr(y), N, H, W, C, TDN_BF16, _lib.stream_ptr()),
+    y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, C, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().tdn_subsample2_fwd(_ptr(x), _ptr(y), N, H, W, C, dtype_code(x.dtype), _lib.stream_ptr()),
                "tdn_subsample2_fwd")
     return y
 
@@ -279,11 +298,11 @@ def subsample2_bwd(dy, in_hw, dx_in=None):
     if (Ho, Wo) != ((H + 1) // 2, (W + 1) // 2):
         raise RuntimeError("subsample bwd: inconsistent shapes")
     if dx_in is not None:
-        _chk_act(dx_in, "dx_in", C)
+        _chk_act(dx_in, "dx_in", C, dy.dtype)
         if tuple(dx_in.shape) != (N, H, W, C):
             raise RuntimeError("subsample bwd: dx_in shape mismatch")
-    dx = torch.empty(N, H, W, C, dtype=BF16, device=dy.device)
-    _lib.check(_lib.load().tdn_subsample2_bwd(_ptr(dy), _ptr(dx_in), _ptr(dx), N, H, W, C, TDN_BF16,
+    dx = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().tdn_subsample2_bwd(_ptr(dy), _ptr(dx_in), _ptr(dx), N, H, W, C, dtype_code(dy.dtype),
                                               _lib.stream_ptr()), "tdn_subsample2_bwd")
     return dx
 
@@ -292,20 +311,21 @@ def add_relu_mask(a, b=None, mask_src=None):
     _chk_act(a, "a")
     for t in (b, mask_src):
         if t is not None:
-            _chk_act(t, "operand")
+            _chk_act(t, "operand", None, a.dtype)
             if t.shape != a.shape:
                 raise RuntimeError("add_relu_mask: shape mismatch")
     out = torch.empty_like(a)
-    _lib.check(_lib.load().tdn_add_relu_mask(_ptr(a), _ptr(b), _ptr(mask_src), _ptr(out), a.numel(), TDN_BF16,
-                                             _lib.stream_ptr()), "tdn_add_relu_mask")
+    _lib.check(_lib.load().tdn_add_relu_mask(_ptr(a), _ptr(b), _ptr(mask_src), _ptr(out), a.numel(),
+                                             dtype_code(a.dtype), _lib.stream_ptr()), "tdn_add_relu_mask")
     return out
 
 
-def to_nhwc_bf16(x):
-    """Logical NCHW tensor -> NHWC bf16 (N,H,W,C). Zero-copy when x already is a permuted NHWC bf16 tensor."""
+def to_nhwc_bf16(x, dtype=BF16):
+    """Logical NCHW tensor -> NHWC `dtype` (N,H,W,C). Zero-copy when x already is a permuted NHWC tensor of that
+    dtype.  (The name is historical: dtype may be torch.float16.)"""
     if x.dim() != 4 or not x.is_cuda:
         raise ValueError("expected a 4-D CUDA tensor, got %s on %s" % (tuple(x.shape), x.device))
-    if x.dtype == BF16:
+    if x.dtype == dtype:
         xp = x.permute(0, 2, 3, 1)
         if xp.is_contiguous():
             return xp
@@ -313,10 +333,10 @@ def to_nhwc_bf16(x):
     if x.dtype != torch.float32:
         x = x.float()
     N, C, H, W = x.shape
-    out = torch.empty(N, H, W, C, dtype=BF16, device=x.device)
+    out = torch.empty(N, H, W, C, dtype=dtype, device=x.device)
     s = x.stride()
-    _lib.check(_lib.load().tdn_nchw_f32_to_nhwc(_ptr(x), s[0], s[1], s[2], s[3], N, C, H, W, _ptr(out), TDN_BF16,
-                                                _lib.stream_ptr()), "tdn_nchw_f32_to_nhwc")
+    _lib.check(_lib.load().tdn_nchw_f32_to_nhwc(_ptr(x), s[0], s[1], s[2], s[3], N, C, H, W, _ptr(out),
+                                                dtype_code(dtype), _lib.stream_ptr()), "tdn_nchw_f32_to_nhwc")
     return out
 
 
@@ -324,8 +344,8 @@ def nhwc_to_nchw_f32(x):
     _chk_act(x, "x")
     N, H, W, C = x.shape
     out = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().tdn_nhwc_to_nchw_f32(_ptr(x), N, C, H, W, _ptr(out), TDN_BF16, _lib.stream_ptr()),
-               "tdn_nhwc_to_nchw_f32")
+    _lib.check(_lib.load().tdn_nhwc_to_nchw_f32(_ptr(x), N, C, H, W, _ptr(out), dtype_code(x.dtype),
+                                                _lib.stream_ptr()), "tdn_nhwc_to_nchw_f32")
     return out
 
 
