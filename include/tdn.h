@@ -198,6 +198,24 @@ int tdn_bbox_normalize(float* bbox, int64_t rows, const float* means4, const flo
 int tdn_bbox_denormalize(const float* bbox, float* out, int64_t rows, int cols, const float* means4,
                          const float* stds4, void* stream);
 
+/* ---- image batch staging -------------------------------------------
+ * One launch for what the reference does per image on the host and then in collate():
+ *   img_normalize            datasets/utils/image.py:87-105     (img - mean) / std, float32
+ *   img_flip (horizontal)    datasets/utils/image.py:220-249
+ *   img_pad_size_divisor     datasets/utils/image.py:300-347    zero pad bottom/right
+ *   HWC -> CHW               datasets/dataset_transforms.py:44
+ *   collate (stack, pad 0)   datasets/loader/collate.py:42-63   pad every sample to the batch maximum
+ * imgs: HOST array of N device pointers to H_i x W_i x 3 pixels (src_kind 0 = uint8, 1 = float32), already resized;
+ * hw: HOST int32 [N][2] = (H_i, W_i); flip: HOST [N] flags or NULL; mean3 / std3: HOST float[3], in the images'
+ * channel order.  Hb x Wb = batch size (>= every image, normally rounded up to the size divisor by the caller).
+ * out_kind 0: float32 (N, 3, Hb, Wb), bit-identical to the reference chain (two IEEE operations per element).
+ * out_kind 1: the stem's staged input (N, Hb+6, Wb+8, 4) in `dtype` — exactly tdn_stage_image of the out_kind-0
+ *             batch, without the float32 round trip.  N <= TDN_COLLATE_MAX per call. */
+#define TDN_COLLATE_MAX 16
+int tdn_collate_images(const void* const* imgs, const int32_t* hw, const uint8_t* flip, int N, int src_kind,
+                       const float* mean3, const float* std3, int Hb, int Wb, void* out, int out_kind, int dtype,
+                       void* stream);
+
 /* ---- host-only introspection (no GPU needed; used by CPU tests) --------------------- */
 
 /* Describes the GEMM decomposition the library would launch for a conv: fills out[0..15] with

@@ -256,6 +256,36 @@ def main():
     man["bbox_norm"] = {"seed4": 900, "seed12": 901, "lo": -3.0, "hi": 3.0,
                         "a": [means, stds], "b": [means2, stds2], "normalize_in_place": True}
 
+    # ---- image batch staging: normalize -> flip -> pad to /32 -> CHW -> collate ------------
+    from datasets.utils.image import img_flip, img_normalize, img_pad_size_divisor
+    from datasets.utils import DataContainer
+    from datasets.loader.collate import collate as ref_collate
+    from oracle import stage_ref as SR
+    rng = np.random.RandomState(1234)
+    sizes_hw = [(37, 50), (40, 41), (64, 33)]
+    imgs = [rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for h, w in sizes_hw]
+    flips = [False, True, True]
+    c_means, c_stds = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)
+    cg = {}
+    for tag, srcs in (("u8", imgs), ("f32", [im.astype(np.float32) * np.float32(0.5) for im in imgs])):
+        samples = []
+        for im, fl in zip(srcs, flips):
+            x = img_normalize(im, np.array(c_means, np.float32), np.array(c_stds, np.float32))
+            x, flag, _ = img_flip(x, 1 if fl else 0)        # flip_prob 1 / 0: deterministic
+            assert flag == fl
+            x = img_pad_size_divisor(x, size_divisor=32)
+            x = x.transpose(2, 0, 1)
+            samples.append(DataContainer(torch.from_numpy(np.ascontiguousarray(x)), stack=True, padding_value=0))
+        out = ref_collate(samples, sample_per_gpu=len(samples)).data[0]
+        mine, pads = SR.np_collate_images(srcs, c_means, c_stds, flips, 32)
+        assert out.dtype == torch.float32 and np.array_equal(out.numpy(), mine), "oracle != reference (collate %s)" % tag
+        cg[tag + "/batch"] = out.numpy()
+        for i, im in enumerate(srcs):
+            cg["%s/img%d" % (tag, i)] = im
+    np.savez_compressed(os.path.join(GOLD, "collate.npz"), **cg)
+    man["collate"] = {"sizes_hw": [list(s) for s in sizes_hw], "flips": flips, "means": list(c_means),
+                      "stds": list(c_stds), "size_divisor": 32, "batch_shape": list(cg["u8/batch"].shape)}
+
     # ---- R50+FPN end-to-end fwd+bwd oracle == reference (small, not stored) ----------------------
     rb = RefResNet(50)
     rf = RefFPN([256, 512, 1024, 2048], 256, 5)

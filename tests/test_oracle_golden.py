@@ -164,3 +164,35 @@ def test_pafpn_oracle_bit_exact(manifest, golden_dir, tag, actv):
         key = "%s/grad/%s" % (tag, k)
         if key in gold:
             assert np.array_equal(p.grad.numpy(), gold[key]), k
+
+
+def test_collate_oracle_vs_reference_golden(manifest, golden_dir):
+    """oracle/stage_ref.py == the reference's normalize -> flip -> pad(/32) -> CHW -> collate chain, bit for bit
+    (golden batch produced by the reference functions themselves, oracle/gen_golden.py), uint8 and float32 pixels."""
+    from oracle import stage_ref as SR
+    man = manifest["collate"]
+    gold = np.load(os.path.join(golden_dir, "collate.npz"))
+    for tag in ("u8", "f32"):
+        imgs = [gold["%s/img%d" % (tag, i)] for i in range(len(man["sizes_hw"]))]
+        assert [list(im.shape[:2]) for im in imgs] == man["sizes_hw"]
+        batch, pads = SR.np_collate_images(imgs, man["means"], man["stds"], man["flips"], man["size_divisor"])
+        assert batch.dtype == np.float32 and list(batch.shape) == man["batch_shape"]
+        assert np.array_equal(batch, gold[tag + "/batch"])
+        assert pads == [(64, 64), (64, 64), (64, 64)]
+    # ragged batch maximum + no divisor: pure collate padding
+    b2, p2 = SR.np_collate_images([np.ones((3, 5, 3), np.uint8), np.ones((4, 2, 3), np.uint8)], (0, 0, 0), (1, 1, 1),
+                                  None, None)
+    assert b2.shape == (2, 3, 4, 5) and p2 == [(3, 5), (4, 2)]
+    assert float(b2.sum()) == 3 * (15 + 8)
+    xp = SR.np_stage(b2)
+    assert xp.shape == (2, 10, 13, 4) and float(xp.sum()) == float(b2.sum()) and float(np.abs(xp[..., 3]).sum()) == 0
+
+
+def test_image_transforms_host_contract():
+    """ImageTransforms keeps the reference constructor (dataset_transforms.py:21-27) and refuses host tensors:
+    there is no CPU fallback for the staging kernel."""
+    import torch_detection_amd as T
+    t = T.ImageTransforms((1., 2., 3.), (4., 5., 6.), size_divisor=32)
+    assert t.img_means.dtype == np.float32 and t.img_stds.tolist() == [4., 5., 6.] and t.size_divisor == 32
+    with pytest.raises(ValueError):
+        t([torch.zeros(4, 4, 3, dtype=torch.uint8)])

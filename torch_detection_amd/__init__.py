@@ -1,7 +1,8 @@
 """torch_detection_amd — MI355X-native ResNet/FPN + box-op hot path behind the Torch_Detection registry.
 
 Drop-in surface (same names as the reference's ``models`` package): ``BACKBONES``, ``NECKS``, ``ResNet``,
-``FPN``, ``ConvModule``, the conv/norm builders and init helpers.  Everything computes through libtdn.so
+``FPN``, ``PAFPN``, ``ConvModule``, the conv/norm builders and init helpers, plus the steps either side of it
+(``ImageTransforms`` device-side batch staging, box ops, ``bbox_normalize`` / ``bbox_denormalize``).  Everything computes through libtdn.so
 (hand-written gfx950 HIP kernels, C ABI in include/tdn.h); there is no CPU or eager fallback.
 """
 __version__ = "0.1.0"
@@ -14,5 +15,6 @@ from .inits import (bias_init_with_prob, constant_init, kaiming_init, normal_ini
 from .checkpoint import load_checkpoint, load_state_dict, save_checkpoint  # noqa: F401
 from .backbone import BasicBlock, Bottleneck, ResNet  # noqa: F401
 from .necks import FPN, PAFPN  # noqa: F401
+from .staging import ImageTransforms, StagedImages  # noqa: F401
 from .box import (AnchorGenerator, bbox_denormalize, bbox_normalize, bbox_overlaps, nms,  # noqa: F401
                   nms_mask)

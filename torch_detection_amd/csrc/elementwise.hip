@@ -428,3 +428,99 @@ extern "C" int tdn_nhwc_to_nchw_f32(const void* src, int N, int C, int H, int W,
   TDN_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- image batch staging: normalize + horizontal flip + zero pad + HWC -> (NCHW f32 | staged NHWC4) + collate ----
+// Replaces, for already-resized pixels, datasets/utils/image.py:87-105 (img_normalize), :220-249 (img_flip),
+// :300-347 (img_pad_size_divisor), dataset_transforms.py:44 (HWC -> CHW) and loader/collate.py:42-63 (pad to the
+// batch maximum, padding_value 0, stack).  (x - mean) / std as two IEEE fp32 operations: bit-identical to numpy.
+struct CollateArgs {
+  const void* img[TDN_COLLATE_MAX];
+  int h[TDN_COLLATE_MAX], w[TDN_COLLATE_MAX];
+  int flip[TDN_COLLATE_MAX];
+  float mean[3], stdv[3];
+  int n, Hb, Wb;
+};
+
+template <bool SRC_F32>
+__device__ __forceinline__ void collate_pixel(const CollateArgs& a, int n, int y, int x, float v[3]) {
+  v[0] = v[1] = v[2] = 0.f;
+  if (y < a.h[n] && x < a.w[n]) {
+    const int sx = a.flip[n] ? a.w[n] - 1 - x : x;
+    const int64_t o = ((int64_t)y * a.w[n] + sx) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float s = SRC_F32 ? ((const float*)a.img[n])[o + c] : (float)((const uint8_t*)a.img[n])[o + c];
+      v[c] = __fdiv_rn(__fsub_rn(s, a.mean[c]), a.stdv[c]);
+    }
+  }
+}
+
+template <bool SRC_F32>
+__global__ void collate_nchw_kernel(const CollateArgs a, float* out) {
+  const int64_t plane = (int64_t)a.Hb * a.Wb, total = plane * a.n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / plane);
+    const int64_t r = i - n * plane;
+    const int y = (int)(r / a.Wb), x = (int)(r - (int64_t)y * a.Wb);
+    float v[3];
+    collate_pixel<SRC_F32>(a, n, y, x, v);
+    float* o = out + (int64_t)n * 3 * plane + r;
+    o[0] = v[0]; o[plane] = v[1]; o[2 * plane] = v[2];
+  }
+}
+
+template <bool SRC_F32, bool F16>
+__global__ void collate_staged_kernel(const CollateArgs a, bf16_t* xp) {
+  const int Hp = a.Hb + 6, Wp = a.Wb + 8;
+  const int64_t total = (int64_t)a.n * Hp * Wp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int wp = (int)(i % Wp);
+    const int64_t r = i / Wp;
+    const int hp = (int)(r % Hp), n = (int)(r / Hp);
+    const int y = hp - 3, x = wp - 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (y >= 0 && y < a.Hb && x >= 0 && x < a.Wb) collate_pixel<SRC_F32>(a, n, y, x, v);
+    bf16x4_t o = {f32_to_elem<F16>(v[0]), f32_to_elem<F16>(v[1]), f32_to_elem<F16>(v[2]), f32_to_elem<F16>(0.f)};
+    *(bf16x4_t*)(xp + i * 4) = o;
+  }
+}
+
+extern "C" int tdn_collate_images(const void* const* imgs, const int32_t* hw, const uint8_t* flip, int N,
+                                  int src_kind, const float* mean3, const float* std3, int Hb, int Wb, void* out,
+                                  int out_kind, int dtype, void* stream) {
+  TDN_CHECK(imgs && hw && mean3 && std3 && out, "tdn_collate_images: NULL pointer");
+  TDN_CHECK(N > 0 && N <= TDN_COLLATE_MAX, "tdn_collate_images: N=%d outside 1..%d (split the batch)", N,
+            TDN_COLLATE_MAX);
+  TDN_CHECK(src_kind == 0 || src_kind == 1, "tdn_collate_images: src_kind %d (0 = u8 HWC, 1 = f32 HWC)", src_kind);
+  TDN_CHECK(out_kind == 0 || out_kind == 1, "tdn_collate_images: out_kind %d (0 = f32 NCHW, 1 = staged)", out_kind);
+  TDN_CHECK(Hb > 0 && Wb > 0, "tdn_collate_images: batch size %dx%d", Hb, Wb);
+  if (out_kind == 1) TDN_CHECK_DTYPE(dtype);
+  CollateArgs a;
+  for (int i = 0; i < N; ++i) {
+    TDN_CHECK(imgs[i] != nullptr, "tdn_collate_images: image %d is NULL", i);
+    a.img[i] = imgs[i];
+    a.h[i] = hw[2 * i];
+    a.w[i] = hw[2 * i + 1];
+    a.flip[i] = flip ? flip[i] : 0;
+    TDN_CHECK(a.h[i] > 0 && a.w[i] > 0 && a.h[i] <= Hb && a.w[i] <= Wb,
+              "tdn_collate_images: image %d is %dx%d, batch is %dx%d", i, a.h[i], a.w[i], Hb, Wb);
+  }
+  for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
+  a.n = N; a.Hb = Hb; a.Wb = Wb;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_kind == 0) {
+    const int64_t total = (int64_t)N * Hb * Wb;
+    if (src_kind) hipLaunchKernelGGL(collate_nchw_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, st, a, (float*)out);
+    else hipLaunchKernelGGL(collate_nchw_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, st, a, (float*)out);
+  } else {
+    const int64_t total = (int64_t)N * (Hb + 6) * (Wb + 8);
+    const dim3 g(grid_for(total, 256)), b(256);
+    const bool f16 = dtype == TDN_F16;
+    if (src_kind && f16) hipLaunchKernelGGL((collate_staged_kernel<true, true>), g, b, 0, st, a, (bf16_t*)out);
+    else if (src_kind) hipLaunchKernelGGL((collate_staged_kernel<true, false>), g, b, 0, st, a, (bf16_t*)out);
+    else if (f16) hipLaunchKernelGGL((collate_staged_kernel<false, true>), g, b, 0, st, a, (bf16_t*)out);
+    else hipLaunchKernelGGL((collate_staged_kernel<false, false>), g, b, 0, st, a, (bf16_t*)out);
+  }
+  TDN_LAUNCH_CHECK();
+  return 0;
+}

@@ -118,12 +118,32 @@ class ConvUnit(object):
         return self
 
 
+class StagedImages(object):
+    """A batch already in the stem kernel's input layout: ``xp`` (N, H+6, W+8, 4) bf16/fp16 with zero halo
+    (``ops.stage_image`` / ``ops.collate_images(staged=True)``), ``hw`` = (H, W) of the padded batch.
+    ``ResNet.forward`` accepts it in place of the float32 (N, 3, H, W) tensor and skips its own staging launch."""
+
+    def __init__(self, xp, hw):
+        H, W = hw
+        if xp.dim() != 4 or tuple(xp.shape[1:]) != (H + 6, W + 8, 4) or xp.dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError('StagedImages: xp %s %s does not match batch size %s' % (tuple(xp.shape), xp.dtype, (H, W)))
+        self.xp, self.hw = xp, (int(H), int(W))
+
+    @property
+    def dtype(self):
+        return self.xp.dtype
+
+    @property
+    def shape(self):
+        return (self.xp.shape[0], 3, self.hw[0], self.hw[1])
+
+
 def pick_dtype(module, x):
     """Compute dtype of a forward call: the input's own 16-bit float dtype when it has one (fp16 in -> fp16 compute,
     like ``model.half()(x.half())`` on the reference), else the module's ``compute_dtype`` attribute (default
     bfloat16).  Parameters stay float32 master copies either way."""
     t = x[0] if isinstance(x, (tuple, list)) else x
-    if t.dtype in (torch.float16, torch.bfloat16):
+    if t.dtype in (torch.float16, torch.bfloat16):   # includes StagedImages
         return t.dtype
     return getattr(module, 'compute_dtype', torch.bfloat16)
 
@@ -354,7 +374,14 @@ class SeqNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, *params):
         st = {}
-        if net.stem is not None:
+        if net.stem is not None and isinstance(x, StagedImages):
+            if x.dtype != net.dtype:
+                raise RuntimeError('staged images are %s but the net computes in %s' % (x.dtype, net.dtype))
+            xp, (H, W) = x.xp, x.hw
+            s = ops.stem_conv_fwd(xp, net.stem.w_fwd, (H, W), net.stem.scale, net.stem.shift, True)
+            cur, idx = ops.maxpool3x3s2_fwd(s)
+            st.update(xp=xp, s=s, idx=idx, img_hw=(H, W))
+        elif net.stem is not None:
             if x.dim() != 4 or x.shape[1] != 3:
                 raise RuntimeError('ResNet expects an (N,3,H,W) image batch, got %s' % (tuple(x.shape),))
             img = x if x.dtype == torch.float32 else x.float()

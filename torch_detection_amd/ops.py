@@ -420,3 +420,54 @@ def nms(boxes, scores, iou_thr):
     _lib.check(lib.tdn_nms(_ptr(boxes), _ptr(scores), N, float(iou_thr), _ptr(keep), _ptr(kept_idx), _ptr(num),
                            ctypes.c_void_p(ws.data_ptr() + off), nbytes, _lib.stream_ptr()), "tdn_nms")
     return keep, kept_idx, num
+
+
+# ---- image batch staging ---------------------------------------------------------------------------
+COLLATE_MAX = 16
+
+
+def collate_images(images, means, stds, flips=None, batch_hw=None, size_divisor=32, staged=False, dtype=BF16):
+    """normalize + flip + zero-pad + HWC->CHW + collate of already-resized images in one launch.
+
+    images: list of CUDA uint8 or float32 tensors (H_i, W_i, 3), contiguous, all of one dtype.
+    Returns float32 (N, 3, Hb, Wb) — or, with ``staged=True``, the stem's input (N, Hb+6, Wb+8, 4) in ``dtype``.
+    Hb, Wb default to the largest image rounded up to ``size_divisor`` (image.py:340-347 + collate.py:52-56)."""
+    N = len(images)
+    if N == 0 or N > COLLATE_MAX:
+        raise ValueError("collate_images takes 1..%d images per call, got %d" % (COLLATE_MAX, N))
+    kind = images[0].dtype
+    if kind not in (torch.uint8, torch.float32):
+        raise ValueError("images must be uint8 or float32, got %s" % (kind,))
+    dev = images[0].device
+    for i, im in enumerate(images):
+        if im.dtype != kind or not im.is_cuda or im.device != dev or im.dim() != 3 or im.shape[2] != 3 or \
+                not im.is_contiguous() or im.numel() == 0:
+            raise ValueError("image %d must be a non-empty contiguous CUDA %s (H, W, 3) tensor on %s, got %s %s %s" %
+                             (i, kind, dev, im.dtype, im.device, tuple(im.shape)))
+    if len(means) != 3 or len(stds) != 3:
+        raise ValueError("means / stds must have 3 entries")
+    d = int(size_divisor) if size_divisor else 1
+    if batch_hw is None:
+        Hb = max(-(-im.shape[0] // d) * d for im in images)
+        Wb = max(-(-im.shape[1] // d) * d for im in images)
+    else:
+        Hb, Wb = batch_hw
+        if any(im.shape[0] > Hb or im.shape[1] > Wb for im in images):
+            raise RuntimeError("collate_images: an image is larger than the batch size %s" % ((Hb, Wb),))
+    if flips is not None and len(flips) != N:
+        raise ValueError("flips must have one flag per image")
+    ptrs = (ctypes.c_void_p * N)(*[im.data_ptr() for im in images])
+    hw = (ctypes.c_int32 * (2 * N))(*[v for im in images for v in (im.shape[0], im.shape[1])])
+    fl = (ctypes.c_uint8 * N)(*[1 if f else 0 for f in flips]) if flips is not None else None
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in means])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in stds])
+    if staged:
+        out = torch.empty(N, Hb + 6, Wb + 8, 4, dtype=dtype, device=dev)
+        code = dtype_code(dtype)
+    else:
+        out = torch.empty(N, 3, Hb, Wb, dtype=torch.float32, device=dev)
+        code = TDN_BF16
+    _lib.check(_lib.load().tdn_collate_images(ptrs, hw, fl, N, 0 if kind == torch.uint8 else 1, m3, s3, Hb, Wb,
+                                              _ptr(out), 1 if staged else 0, code, _lib.stream_ptr()),
+               "tdn_collate_images")
+    return out
