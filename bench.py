@@ -162,7 +162,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=32)
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="world size 1 only: run the N>1 code path (RCCL process group, bucketed reducer inside the "
+                         "captured step) on a single GPU — a rehearsal of what --gpus N executes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,10 +179,25 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_reducer
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is one JSON line
+        # on stdout, so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from torch_detection_amd import dp, ops
     backbone, neck = build_models(args.depth, device)
@@ -204,7 +222,7 @@ def main():
     del outs
 
     reducer = dp.attach_reducer([neck, backbone], bucket_bytes=args.bucket_mb << 20, dtype=cdtype) \
-        if world > 1 else None
+        if use_dist else None
     params = list(backbone.parameters()) + list(neck.parameters())
 
     def step():
@@ -221,9 +239,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- execution mode: one hipGraph per step (single GPU) or eager launches (multi-GPU: RCCL stays eager) ----
+    # ---- execution mode: the whole step — forward, backward and (N > 1) the bucketed RCCL all-reduces on their
+    # comm stream — captured once into a hipGraph and replayed; eager launches if capture is refused ----
     graph, mode = None, "eager"
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = not args.no_graph
     if use_graph:
         try:
             side = torch.cuda.Stream()
@@ -236,7 +255,8 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 step()
-            mode = "hipGraph replay (one captured fwd+bwd step; wgrad kernels on a forked side stream)"
+            mode = "hipGraph replay (one captured fwd+bwd step; wgrad kernels on forked side streams%s)" % (
+                "; bucketed RCCL all-reduce nodes on a comm stream inside the graph" if use_dist else "")
         except Exception as e:  # noqa: BLE001 - fall back loudly, never silently
             print("bench.py: hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
             graph, mode = None, "eager (graph capture failed)"
@@ -314,7 +334,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.depth)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -58,28 +58,35 @@ class GradReducer(object):
     def reset(self):
         self._pending = [b[2] for b in self.buckets]
         self._works = []
+        self._producers = [[] for _ in self.buckets]   # streams that wrote into each bucket this step
 
     def mark_ready(self, slot, stream=None):
         """Slot's gradient has been enqueued on ``stream`` (default: the current stream); launch its bucket's
         all-reduce if complete."""
         b = self.bucket_of[slot]
         self._pending[b] -= 1
+        if self.use_streams:
+            st = stream if stream is not None else torch.cuda.current_stream(self.device)
+            if all(st != q for q in self._producers[b]):
+                self._producers[b].append(st)
         if self._pending[b] == 0:
-            self._launch(b, stream)
+            self._launch(b)
         elif self._pending[b] < 0:
             raise RuntimeError('GradReducer: slot %d marked ready twice in one step (call reset()/finish())' % slot)
 
-    def _launch(self, b, stream=None):
+    def _launch(self, b):
         start, end, _ = self.buckets[b]
         buf = self.flat[start:end]
         if not self.enabled:
             return
         if self.use_streams:
-            # every gradient of the bucket was produced on `stream` (the wgrad side stream) or, when a bucket is
-            # flushed from finish(), on streams the current stream has already joined
-            ev = torch.cuda.Event()
-            ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
-            self.comm_stream.wait_event(ev)
+            # the bucket's gradients were produced on several streams (the weight-gradient kernels rotate over a
+            # pool of side streams): the comm stream waits for every one of them — and for the current stream, which
+            # covers buckets flushed from finish() and gradients written by the main stream
+            for st in self._producers[b] + [torch.cuda.current_stream(self.device)]:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
