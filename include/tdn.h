@@ -198,6 +198,23 @@ int tdn_bbox_normalize(float* bbox, int64_t rows, const float* means4, const flo
 int tdn_bbox_denormalize(const float* bbox, float* out, int64_t rows, int cols, const float* means4,
                          const float* stds4, void* stream);
 
+/* ---- GroupNorm ----------------------------------------------------
+ * nn.GroupNorm(get_group_gn(planes), planes) — models/utils/layers.py:50-54,138-154 (32 groups, eps 1e-5, biased
+ * variance) — after a conv of ResNet(use_gn=True) (models/backbone/resnet.py:42-59,97-119,254-257) or of a
+ * ConvModule with GN (layers.py:122-135), fused with the residual add and ReLU that follow it.
+ *   tdn_gn_fwd: z (N,H,W,C) raw conv output -> y = relu?((z - mu) * rstd * gamma + beta (+ addend, same shape));
+ *               stats (N,C,2) float = per-channel (mu, rstd) of the channel's group, kept for the backward.
+ *   tdn_gn_bwd: g = dL/dy (already ReLU-masked) -> dz = dL/dz (16-bit, feeds tdn_conv2d_dgrad / _wgrad with no BN
+ *               fold), dgamma, dbeta (float; acc = 1 accumulates into them, 0 overwrites).
+ * C a power of two in 64..2048, G | C.  workspace: tdn_gn_workspace() bytes, 16-byte aligned. */
+int64_t tdn_gn_workspace(int N, int H, int W, int C, int G);
+int tdn_gn_fwd(const void* z, const float* gamma, const float* beta, int N, int H, int W, int C, int G, float eps,
+               const void* addend, int relu, void* y, float* stats, void* workspace, int64_t workspace_bytes,
+               int dtype, void* stream);
+int tdn_gn_bwd(const void* g, const void* z, const float* stats, const float* gamma, int N, int H, int W, int C,
+               int G, void* dz, float* dgamma, float* dbeta, float acc, void* workspace, int64_t workspace_bytes,
+               int dtype, void* stream);
+
 /* ---- image batch staging -------------------------------------------
  * One launch for what the reference does per image on the host and then in collate():
  *   img_normalize            datasets/utils/image.py:87-105     (img - mean) / std, float32

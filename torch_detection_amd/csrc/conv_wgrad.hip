@@ -321,7 +321,7 @@ static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps) {
   w.bnw = (Ktap % 64 == 0) ? 64 : 32;
   if (const char* env = getenv("TDN_WGRAD_TILE")) {   // tuning override: "BMWxBNW" with 64/128 entries
     int a = 0, b = 0;
-    if (sscanf(env, "%dx%d", &a, &b) == 2 && (a == 64 || a == 128 || a == 256) && (b == 64 || b == 128) &&
+    if (sscanf(env, "%dx%d", &a, &b) == 2 && (a == 64 || a == 128 || a == 256) && (b == 64 || b == 128 || b == 256) &&
         Cout % a == 0 && Ktap % b == 0) {
       w.bmw = a;
       w.bnw = b;
@@ -391,7 +391,9 @@ static int run_wgrad(WgradParams& p, const WgradPlan& w, const void* w_fwd, cons
   p.M = w.M; p.Mchunk = w.mchunk; p.splitk = w.splitk; p.Ktot = w.Ktot;
   p.tiles_co = w.tiles_co; p.tiles_k = w.tiles_k;
   int rc;
-  if (w.bmw == 256 && w.bnw == 128) rc = launch_wgrad<256, 128, 4, 2>(p, stream, dtype);
+  if (w.bmw == 256 && w.bnw == 256) rc = launch_wgrad<256, 256, 4, 4>(p, stream, dtype);
+  else if (w.bmw == 256 && w.bnw == 128) rc = launch_wgrad<256, 128, 4, 4>(p, stream, dtype);
+  else if (w.bmw == 128 && w.bnw == 256) rc = launch_wgrad<128, 256, 4, 4>(p, stream, dtype);
   else if (w.bmw == 256 && w.bnw == 64) rc = launch_wgrad<256, 64, 4, 2>(p, stream, dtype);
   else if (w.bmw == 128 && w.bnw == 128) rc = launch_wgrad<128, 128>(p, stream, dtype);
   else if (w.bmw == 128 && w.bnw == 64) rc = launch_wgrad<128, 64>(p, stream, dtype);

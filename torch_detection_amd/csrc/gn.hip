@@ -1,0 +1,301 @@
+// GroupNorm forward / backward on NHWC 16-bit activations (gfx950).
+//
+// Replaces nn.GroupNorm(get_group_gn(planes), planes) as built by models/utils/layers.py:50-54,138-154 (32 groups)
+// and applied after the convs of models/backbone/resnet.py (use_gn=True: :42-59, :97-119, :254-257) and of ConvModule
+// (layers.py:122-135, necks with normalize=GN), together with the residual add and ReLU that follow it.
+// Unlike eval-mode BatchNorm the statistics depend on the sample, so GN cannot be folded into the conv epilogue:
+//   forward   z = conv(x) (raw, 16-bit)  ->  [1] per-channel partial (sum, sum of squares) over pixel chunks
+//             -> [2] per (sample, group) mean / rstd, expanded to per-(sample, channel) affine (a, b)
+//             -> [3] y = relu?(z*a + b (+ addend))
+//   backward  g = dL/dy (ReLU-masked) -> [1'] per-channel partial (sum g, sum g*xhat) -> [2'] dgamma, dbeta and the
+//             per-(sample, channel) coefficients of dz = g*A + z*B + C  ->  [3'] dz, which then feeds the ordinary
+//             conv dgrad / wgrad kernels.
+// All three passes are HBM-bound streams, 16 bytes (8 channels) per lane; reductions are fixed-order (deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct GnGeom {
+  int N, HW, C, G, cpg;      // cpg = C / G channels per group
+  int C8;                    // C / 8 lanes per pixel
+  int ppp;                   // pixels per pass of one 256-thread block
+  int chunks, chunk_px;      // pixel chunks per sample, pixels per chunk
+};
+
+// [1] / [1']: partial per-channel sums over one pixel chunk of one sample.
+//   MODE 0: (sum z, sum z^2)            MODE 1: (sum g, sum g * xhat), xhat = z*rstd - mu*rstd from `stats`
+// part layout: [n][chunk][2][C]
+template <int MODE, bool F16>
+__global__ __launch_bounds__(kThreads) void gn_partial_kernel(const bf16_t* __restrict__ z,
+                                                               const bf16_t* __restrict__ g,
+                                                               const float* __restrict__ stats, GnGeom ge,
+                                                               float* __restrict__ part) {
+  __shared__ float red[kThreads][17];
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int cl = tid % ge.C8, pl = tid / ge.C8;   // channel lane (8 channels), pixel lane
+  const int p0 = chunk * ge.chunk_px;
+  const int p1 = min(ge.HW, p0 + ge.chunk_px);
+  float a0[8], a1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+  float mu_r[8], rs[8];
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float mu = stats[((int64_t)n * ge.C + cl * 8 + e) * 2], r = stats[((int64_t)n * ge.C + cl * 8 + e) * 2 + 1];
+      rs[e] = r;
+      mu_r[e] = mu * r;
+    }
+  }
+  const int64_t base = (int64_t)n * ge.HW * ge.C + cl * 8;
+  for (int p = p0 + pl; p < p1; p += ge.ppp) {
+    const bf16x8_t zv = *(const bf16x8_t*)(z + base + (int64_t)p * ge.C);
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = elem_to_f32<F16>(zv[e]);
+        a0[e] += v;
+        a1[e] += v * v;
+      }
+    } else {
+      const bf16x8_t gv = *(const bf16x8_t*)(g + base + (int64_t)p * ge.C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float gg = elem_to_f32<F16>(gv[e]);
+        const float xh = elem_to_f32<F16>(zv[e]) * rs[e] - mu_r[e];
+        a0[e] += gg;
+        a1[e] += gg * xh;
+      }
+    }
+  }
+  // combine the pixel lanes in lane order (fixed order -> deterministic)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[tid][e] = a0[e]; red[tid][8 + e] = a1[e]; }
+  __syncthreads();
+  if (pl == 0) {
+    for (int j = 1; j < ge.ppp; ++j) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[tid][e] += red[j * ge.C8 + cl][e];
+    }
+    float* o = part + (((int64_t)n * ge.chunks + chunk) * 2) * ge.C + cl * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] = red[tid][e]; o[ge.C + e] = red[tid][8 + e]; }
+  }
+}
+
+// [2]: one block per sample; thread per channel (strided): chunk sums -> group mean / rstd (double), then per-channel
+// stats[n][c] = (mu, rstd) and coef[n][c] = (a, b) with y = z*a + b.
+__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const float* __restrict__ part, GnGeom ge,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            float* __restrict__ stats, float* __restrict__ coef) {
+  extern __shared__ double sh[];   // [2][C]
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < ge.C; c += blockDim.x) {
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < ge.chunks; ++k) {
+      const float* q = part + (((int64_t)n * ge.chunks + k) * 2) * ge.C + c;
+      s += (double)q[0];
+      ss += (double)q[ge.C];
+    }
+    sh[c] = s;
+    sh[ge.C + c] = ss;
+  }
+  __syncthreads();
+  const double cnt = (double)ge.HW * ge.cpg;
+  for (int c = threadIdx.x; c < ge.C; c += blockDim.x) {
+    const int g0 = (c / ge.cpg) * ge.cpg;
+    double s = 0.0, ss = 0.0;
+    for (int j = 0; j < ge.cpg; ++j) { s += sh[g0 + j]; ss += sh[ge.C + g0 + j]; }
+    const double mu = s / cnt;
+    double var = ss / cnt - mu * mu;       // biased variance, like nn.GroupNorm
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float muf = (float)mu;
+    stats[((int64_t)n * ge.C + c) * 2] = muf;
+    stats[((int64_t)n * ge.C + c) * 2 + 1] = rstd;
+    const float a = rstd * gamma[c];
+    coef[((int64_t)n * ge.C + c) * 2] = a;
+    coef[((int64_t)n * ge.C + c) * 2 + 1] = beta[c] - muf * a;
+  }
+}
+
+// [3]: y = relu?(z*a + b (+ addend))
+template <bool F16>
+__global__ void gn_apply_kernel(const bf16_t* __restrict__ z, const float* __restrict__ coef,
+                                const bf16_t* __restrict__ addend, int relu, GnGeom ge, bf16_t* __restrict__ y) {
+  const int64_t per_n = (int64_t)ge.HW * ge.C8, total = per_n * ge.N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per_n);
+    const int cl = (int)(i % ge.C8);
+    const bf16x8_t zv = *(const bf16x8_t*)(z + i * 8);
+    const float* cf = coef + ((int64_t)n * ge.C + cl * 8) * 2;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = elem_to_f32<F16>(zv[e]) * cf[2 * e] + cf[2 * e + 1];
+    if (addend) {
+      const bf16x8_t av = *(const bf16x8_t*)(addend + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += elem_to_f32<F16>(av[e]);
+    }
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f32_to_elem<F16>(relu ? fmaxf(v[e], 0.f) : v[e]);
+    *(bf16x8_t*)(y + i * 8) = o;
+  }
+}
+
+// [2']: blocks of 256 consecutive channels (whole groups: cpg divides 256); per sample: chunk sums -> (s1, s2),
+// group means m1 = sum_c gamma*s1 / cnt, m2 = sum_c gamma*s2 / cnt, coefficients of dz = g*A + z*B + Cc;
+// across samples: dgamma = sum_n s2, dbeta = sum_n s1.
+__global__ __launch_bounds__(kThreads) void gn_bwd_coef_kernel(const float* __restrict__ part, GnGeom ge,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ stats,
+                                                               float* __restrict__ coef3, float* dgamma, float* dbeta,
+                                                               float acc) {
+  __shared__ float t1[kThreads], t2[kThreads];
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  const bool live = c < ge.C;
+  const float gm = live ? gamma[c] : 0.f;
+  float dg = 0.f, db = 0.f;
+  const float cnt = (float)ge.HW * (float)ge.cpg;
+  for (int n = 0; n < ge.N; ++n) {
+    float s1 = 0.f, s2 = 0.f;
+    if (live) {
+      for (int k = 0; k < ge.chunks; ++k) {
+        const float* q = part + (((int64_t)n * ge.chunks + k) * 2) * ge.C + c;
+        s1 += q[0];
+        s2 += q[ge.C];
+      }
+    }
+    dg += s2;
+    db += s1;
+    t1[threadIdx.x] = gm * s1;
+    t2[threadIdx.x] = gm * s2;
+    __syncthreads();
+    if (live) {
+      const int l0 = (threadIdx.x / ge.cpg) * ge.cpg;
+      float m1 = 0.f, m2 = 0.f;
+      for (int j = 0; j < ge.cpg; ++j) { m1 += t1[l0 + j]; m2 += t2[l0 + j]; }
+      m1 /= cnt;
+      m2 /= cnt;
+      const float mu = stats[((int64_t)n * ge.C + c) * 2], r = stats[((int64_t)n * ge.C + c) * 2 + 1];
+      float* o = coef3 + ((int64_t)n * ge.C + c) * 3;
+      o[0] = r * gm;                       // A
+      o[1] = -r * r * m2;                  // B
+      o[2] = -r * m1 + mu * r * r * m2;    // C
+    }
+    __syncthreads();
+  }
+  if (live) {
+    dgamma[c] = (acc != 0.f) ? acc * dgamma[c] + dg : dg;
+    dbeta[c] = (acc != 0.f) ? acc * dbeta[c] + db : db;
+  }
+}
+
+// [3']: dz = g*A + z*B + C
+template <bool F16>
+__global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ z,
+                                    const float* __restrict__ coef3, GnGeom ge, bf16_t* __restrict__ dz) {
+  const int64_t per_n = (int64_t)ge.HW * ge.C8, total = per_n * ge.N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per_n);
+    const int cl = (int)(i % ge.C8);
+    const bf16x8_t gv = *(const bf16x8_t*)(g + i * 8);
+    const bf16x8_t zv = *(const bf16x8_t*)(z + i * 8);
+    const float* cf = coef3 + ((int64_t)n * ge.C + cl * 8) * 3;
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e] = f32_to_elem<F16>(elem_to_f32<F16>(gv[e]) * cf[3 * e] + elem_to_f32<F16>(zv[e]) * cf[3 * e + 1] +
+                              cf[3 * e + 2]);
+    *(bf16x8_t*)(dz + i * 8) = o;
+  }
+}
+
+int make_geom(GnGeom& ge, int N, int H, int W, int C, int G) {
+  TDN_CHECK(N > 0 && H > 0 && W > 0, "GroupNorm: bad shape N=%d H=%d W=%d", N, H, W);
+  TDN_CHECK(C >= 64 && C <= 2048 && (C & (C - 1)) == 0, "GroupNorm: C=%d must be a power of two in 64..2048", C);
+  TDN_CHECK(G > 0 && C % G == 0, "GroupNorm: %d groups do not divide %d channels", G, C);
+  ge.N = N; ge.HW = H * W; ge.C = C; ge.G = G; ge.cpg = C / G;
+  TDN_CHECK((ge.cpg & (ge.cpg - 1)) == 0 && ge.cpg <= 256, "GroupNorm: %d channels per group not supported", ge.cpg);
+  ge.C8 = C / 8;
+  ge.ppp = kThreads / ge.C8;
+  int chunks = ceil_div(1024, N);                       // ~1024 blocks in flight
+  const int max_chunks = ceil_div(ge.HW, ge.ppp * 4);   // at least 4 passes per block
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  ge.chunk_px = ceil_div(ge.HW, chunks);
+  ge.chunks = ceil_div(ge.HW, ge.chunk_px);
+  return 0;
+}
+
+// workspace: part [N][chunks][2][C] floats | coef [N][C][3] floats
+int64_t ws_floats(const GnGeom& ge) { return (int64_t)ge.N * ge.chunks * 2 * ge.C + (int64_t)ge.N * ge.C * 3; }
+
+}  // namespace
+
+extern "C" int64_t tdn_gn_workspace(int N, int H, int W, int C, int G) {
+  GnGeom ge;
+  if (make_geom(ge, N, H, W, C, G)) return -1;
+  return ws_floats(ge) * 4 + 256;
+}
+
+extern "C" int tdn_gn_fwd(const void* z, const float* gamma, const float* beta, int N, int H, int W, int C, int G,
+                          float eps, const void* addend, int relu, void* y, float* stats, void* workspace,
+                          int64_t workspace_bytes, int dtype, void* stream) {
+  TDN_CHECK_DTYPE(dtype);
+  TDN_CHECK(z && gamma && beta && y && stats && workspace, "tdn_gn_fwd: NULL pointer");
+  GnGeom ge;
+  if (make_geom(ge, N, H, W, C, G)) return -1;
+  TDN_CHECK(workspace_bytes >= ws_floats(ge) * 4 && ((uintptr_t)workspace & 15) == 0,
+            "tdn_gn_fwd: workspace too small or misaligned");
+  float* part = (float*)workspace;
+  float* coef = part + (int64_t)ge.N * ge.chunks * 2 * ge.C;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 gp(ge.chunks, N);
+  if (dtype == TDN_F16)
+    hipLaunchKernelGGL((gn_partial_kernel<0, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
+  else
+    hipLaunchKernelGGL((gn_partial_kernel<0, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(N), dim3(kThreads), 2 * C * sizeof(double), st, part, ge, gamma, beta, eps,
+                     stats, coef);
+  const int64_t total = (int64_t)N * ge.HW * ge.C8;
+  int grid = (int)((total + kThreads - 1) / kThreads);
+  if (grid > 8192) grid = 8192;
+  TDN_LAUNCH_T(gn_apply_kernel, dtype, dim3(grid), dim3(kThreads), st, (const bf16_t*)z, coef, (const bf16_t*)addend,
+               relu, ge, (bf16_t*)y);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tdn_gn_bwd(const void* g, const void* z, const float* stats, const float* gamma, int N, int H, int W,
+                          int C, int G, void* dz, float* dgamma, float* dbeta, float acc, void* workspace,
+                          int64_t workspace_bytes, int dtype, void* stream) {
+  TDN_CHECK_DTYPE(dtype);
+  TDN_CHECK(g && z && stats && gamma && dz && dgamma && dbeta && workspace, "tdn_gn_bwd: NULL pointer");
+  GnGeom ge;
+  if (make_geom(ge, N, H, W, C, G)) return -1;
+  TDN_CHECK(workspace_bytes >= ws_floats(ge) * 4 && ((uintptr_t)workspace & 15) == 0,
+            "tdn_gn_bwd: workspace too small or misaligned");
+  float* part = (float*)workspace;
+  float* coef3 = part + (int64_t)ge.N * ge.chunks * 2 * ge.C;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 gp(ge.chunks, N);
+  if (dtype == TDN_F16)
+    hipLaunchKernelGGL((gn_partial_kernel<1, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
+  else
+    hipLaunchKernelGGL((gn_partial_kernel<1, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(ceil_div(C, kThreads)), dim3(kThreads), 0, st, part, ge, gamma, stats,
+                     coef3, dgamma, dbeta, acc);
+  const int64_t total = (int64_t)N * ge.HW * ge.C8;
+  int grid = (int)((total + kThreads - 1) / kThreads);
+  if (grid > 8192) grid = 8192;
+  TDN_LAUNCH_T(gn_bwd_apply_kernel, dtype, dim3(grid), dim3(kThreads), st, (const bf16_t*)g, (const bf16_t*)z, coef3,
+               ge, (bf16_t*)dz);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}

@@ -471,3 +471,54 @@ def collate_images(images, means, stds, flips=None, batch_hw=None, size_divisor=
                                               _ptr(out), 1 if staged else 0, code, _lib.stream_ptr()),
                "tdn_collate_images")
     return out
+
+
+# ---- GroupNorm ----------------------------------------------------------------------------------------
+def _gn_ws(N, H, W, C, G, device):
+    nbytes = _lib.load().tdn_gn_workspace(N, H, W, C, G)
+    if nbytes < 0:
+        _lib.check(-1, "tdn_gn_workspace")
+    return _workspace(nbytes, device)
+
+
+def gn_fwd(z, gamma, beta, groups, eps=1e-5, addend=None, relu=False):
+    """y = relu?(GroupNorm(z) (+ addend)) on an NHWC raw conv output; returns (y, stats) with stats (N, C, 2) float32
+    = per-channel (mean, rstd) for the backward."""
+    _chk_act(z, "z")
+    N, H, W, C = z.shape
+    _chk_vec(gamma.detach(), "gamma", C)
+    _chk_vec(beta.detach(), "beta", C)
+    if addend is not None:
+        _chk_act(addend, "addend", C, z.dtype)
+        if addend.shape != z.shape:
+            raise RuntimeError("gn_fwd: addend shape %s != %s" % (tuple(addend.shape), tuple(z.shape)))
+    y = torch.empty_like(z)
+    stats = torch.empty(N, C, 2, dtype=torch.float32, device=z.device)
+    ws = _gn_ws(N, H, W, C, groups, z.device)
+    _lib.check(_lib.load().tdn_gn_fwd(_ptr(z), _ptr(gamma), _ptr(beta), N, H, W, C, int(groups), float(eps),
+                                      _ptr(addend), 1 if relu else 0, _ptr(y), _ptr(stats), _ptr(ws), ws.numel(),
+                                      dtype_code(z.dtype), _lib.stream_ptr()), "tdn_gn_fwd")
+    return y, stats
+
+
+def gn_bwd(g, z, stats, gamma, groups, dgamma=None, dbeta=None, accumulate=False):
+    """(dz, dgamma, dbeta) from g = dL/dy (ReLU mask already applied)."""
+    _chk_act(z, "z")
+    _chk_act(g, "g", z.shape[3], z.dtype)
+    N, H, W, C = z.shape
+    if g.shape != z.shape or tuple(stats.shape) != (N, C, 2) or stats.dtype != torch.float32:
+        raise RuntimeError("gn_bwd: inconsistent shapes g=%s z=%s stats=%s" %
+                           (tuple(g.shape), tuple(z.shape), tuple(stats.shape)))
+    _chk_vec(gamma.detach(), "gamma", C)
+    if dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
+    if dbeta is None:
+        dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
+    _chk_vec(dgamma, "dgamma", C)
+    _chk_vec(dbeta, "dbeta", C)
+    dz = torch.empty_like(z)
+    ws = _gn_ws(N, H, W, C, groups, z.device)
+    _lib.check(_lib.load().tdn_gn_bwd(_ptr(g), _ptr(z), _ptr(stats), _ptr(gamma), N, H, W, C, int(groups), _ptr(dz),
+                                      _ptr(dgamma), _ptr(dbeta), 1.0 if accumulate else 0.0, _ptr(ws), ws.numel(),
+                                      dtype_code(z.dtype), _lib.stream_ptr()), "tdn_gn_bwd")
+    return dz, dgamma, dbeta
