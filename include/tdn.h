@@ -202,14 +202,16 @@ int tdn_bbox_denormalize(const float* bbox, float* out, int64_t rows, int cols, 
  * nn.GroupNorm(get_group_gn(planes), planes) — models/utils/layers.py:50-54,138-154 (32 groups, eps 1e-5, biased
  * variance) — after a conv of ResNet(use_gn=True) (models/backbone/resnet.py:42-59,97-119,254-257) or of a
  * ConvModule with GN (layers.py:122-135), fused with the residual add and ReLU that follow it.
- *   tdn_gn_fwd: z (N,H,W,C) raw conv output -> y = relu?((z - mu) * rstd * gamma + beta (+ addend, same shape));
+ *   tdn_gn_fwd: z (N,H,W,C) raw conv output -> y = relu?((z - mu) * rstd * gamma + beta (+ addend)); addend_mode
+ *               TDN_ADD_SAME (same shape: the residual) or TDN_ADD_UP2X ((N,H/2,W/2,C): FPN top-down, fpn.py:98-100);
  *               stats (N,C,2) float = per-channel (mu, rstd) of the channel's group, kept for the backward.
  *   tdn_gn_bwd: g = dL/dy (already ReLU-masked) -> dz = dL/dz (16-bit, feeds tdn_conv2d_dgrad / _wgrad with no BN
  *               fold), dgamma, dbeta (float; acc = 1 accumulates into them, 0 overwrites).
  * C a power of two in 64..2048, G | C.  workspace: tdn_gn_workspace() bytes, 16-byte aligned. */
 int64_t tdn_gn_workspace(int N, int H, int W, int C, int G);
 int tdn_gn_fwd(const void* z, const float* gamma, const float* beta, int N, int H, int W, int C, int G, float eps,
-               const void* addend, int relu, void* y, float* stats, void* workspace, int64_t workspace_bytes,
+               const void* addend, int addend_mode, int relu, void* y, float* stats, void* workspace,
+               int64_t workspace_bytes,
                int dtype, void* stream);
 int tdn_gn_bwd(const void* g, const void* z, const float* stats, const float* gamma, int N, int H, int W, int C,
                int G, void* dz, float* dgamma, float* dbeta, float acc, void* workspace, int64_t workspace_bytes,

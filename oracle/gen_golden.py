@@ -256,6 +256,81 @@ def main():
     man["bbox_norm"] = {"seed4": 900, "seed12": 901, "lo": -3.0, "hi": 3.0,
                         "a": [means, stds], "b": [means2, stds2], "normalize_in_place": True}
 
+    # ---- GroupNorm variants: use_gn blocks, GN FPN, GN ResNet-18 ------------------------
+    gn = {}
+    gcases = {
+        "bottleneck_s1_nodown": (ref_resnet.Bottleneck, 256, 64, 1, (2, 10, 12)),
+        "bottleneck_s2_down": (ref_resnet.Bottleneck, 128, 64, 2, (2, 9, 12)),
+        "basic_s2_down": (ref_resnet.BasicBlock, 64, 128, 2, (2, 10, 11)),
+    }
+    for ci, (name, (cls, inpl, planes, stride, (n, h, w))) in enumerate(sorted(gcases.items())):
+        blk = ref_resnet._make_res_layer(cls, inpl, planes, 1, stride=stride, use_gn=True)[0]
+        sd = fill_state_dict(blk.state_dict(), 1300 + ci)
+        blk.load_state_dict(sd)
+        x = det_tensor((n, inpl, h, w), 1400 + ci, -1.0, 1.0).requires_grad_(True)
+        y = blk(x)
+        dy = det_tensor(tuple(y.shape), 1500 + ci, -1.0, 1.0)
+        y.backward(dy)
+        fn = O._basic_block if cls is ref_resnet.BasicBlock else O._bottleneck
+        ps = {("b." + k): v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = fn(x2, ps, "b", stride, 1, blk.downsample is not None)
+        y2.backward(dy)
+        assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad), "oracle != reference (GN %s)" % name
+        for k, p in blk.named_parameters():
+            assert torch.equal(ps["b." + k].grad, p.grad), "oracle grad != reference (GN %s %s)" % (name, k)
+        gn["blk/" + name + "/y"] = y.detach().numpy()
+        gn["blk/" + name + "/dx"] = x.grad.numpy()
+        for k, p in blk.named_parameters():
+            gn["blk/" + name + "/grad/" + k] = p.grad.numpy()
+        man.setdefault("gn_blocks", {})[name] = {
+            "cls": cls.__name__, "inplanes": inpl, "planes": planes, "stride": stride, "x_shape": [n, inpl, h, w],
+            "state_seed": 1300 + ci, "x_seed": 1400 + ci, "dy_seed": 1500 + ci, "state_keys": manifest_of(blk)}
+    # FPN with GroupNorm ConvModules (normalize given, use_gn=True: fpn.py:18-19,40-58)
+    gfpn = RefFPN(chans, 64, 5, normalize=dict(type="GN"), use_gn=True)
+    sd = fill_state_dict(gfpn.state_dict(), 1600)
+    gfpn.load_state_dict(sd)
+    ins = [det_tensor((2, c, h, w), 1610 + i, -1.0, 1.0).requires_grad_(True) for i, (c, (h, w)) in
+           enumerate(zip(chans, sizes))]
+    outs = gfpn(ins)
+    cots = [det_tensor(tuple(o.shape), 1620 + i, -1.0, 1.0) for i, o in enumerate(outs)]
+    torch.autograd.backward(outs, cots)
+    ps = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    ins2 = [t.detach().clone().requires_grad_(True) for t in ins]
+    outs2 = O.fpn_forward(ps, ins2, 5)
+    torch.autograd.backward(outs2, cots)
+    for a_, b_ in zip(outs, outs2):
+        assert torch.equal(a_, b_), "oracle != reference (GN FPN forward)"
+    for a_, b_ in zip(ins, ins2):
+        assert torch.equal(a_.grad, b_.grad), "oracle != reference (GN FPN input grad)"
+    for k, p in gfpn.named_parameters():
+        assert torch.equal(ps[k].grad, p.grad), "oracle != reference (GN FPN grad %s)" % k
+    for i, o in enumerate(outs):
+        gn["fpn/out%d" % i] = o.detach().numpy()
+    for i, t in enumerate(ins):
+        gn["fpn/din%d" % i] = t.grad.numpy()
+    for k, p in gfpn.named_parameters():
+        gn["fpn/grad/" + k] = p.grad.numpy()
+    man["gn_fpn_small"] = {"in_channels": chans, "out_channels": 64, "num_outs": 5, "sizes": [list(s_) for s_ in sizes],
+                           "N": 2, "state_seed": 1600, "in_seed0": 1610, "cot_seed0": 1620,
+                           "state_keys": manifest_of(gfpn)}
+    # whole GN backbone forward (stem GN + max pool + BasicBlocks): outputs only
+    m = RefResNet(18, use_gn=True)
+    sd = fill_state_dict(m.state_dict(), 1700)
+    m.load_state_dict(sd)
+    m.train()
+    x = det_tensor((2, 3, 64, 96), 1701, -2.0, 2.0)
+    with torch.no_grad():
+        ref = m(x)
+        mine = O.resnet_forward(sd, x, 18)
+    for a_, b_ in zip(ref, mine):
+        assert torch.equal(a_, b_), "oracle != reference (GN R18 forward)"
+    for i, t in enumerate(ref):
+        gn["r18/c%d" % (i + 2)] = t.numpy()
+    man["gn_resnet18"] = {"input": {"shape": [2, 3, 64, 96], "seed": 1701, "lo": -2.0, "hi": 2.0}, "state_seed": 1700,
+                          "state_keys": manifest_of(m), "out_shapes": [list(t.shape) for t in ref]}
+    np.savez_compressed(os.path.join(GOLD, "gn.npz"), **gn)
+
     # ---- image batch staging: normalize -> flip -> pad to /32 -> CHW -> collate ------------
     from datasets.utils.image import img_flip, img_normalize, img_pad_size_divisor
     from datasets.utils import DataContainer

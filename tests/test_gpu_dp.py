@@ -21,12 +21,17 @@ def _free_port():
     return p
 
 
-def test_bucketed_reducer_single_rank_rccl():
+@pytest.mark.parametrize("use_gn", [False, True])
+def test_bucketed_reducer_single_rank_rccl(use_gn):
     import torch_detection_amd as T
     from torch_detection_amd import dp
     assert torch.cuda.is_available()
     dev = torch.device("cuda", 0)
-    rb, rf = T.ResNet(18), T.FPN([64, 128, 256, 512], 256, 5)
+    if use_gn:   # GroupNorm units: dgamma / dbeta come from the GN kernel on the main stream, dw from the side streams
+        rb = T.ResNet(18, use_gn=True)
+        rf = T.FPN([64, 128, 256, 512], 256, 5, normalize=dict(type="GN"), use_gn=True)
+    else:
+        rb, rf = T.ResNet(18), T.FPN([64, 128, 256, 512], 256, 5)
     rb.load_state_dict(fill_state_dict(rb.state_dict(), 50))
     rf.load_state_dict(fill_state_dict(rf.state_dict(), 51))
     rb.to(dev).train()

@@ -52,6 +52,12 @@ def test_gn_fwd_bwd(ops, case, dt):
     # no addend, no relu
     y0, _ = ops.gn_fwd(nh(z), gamma.detach().cuda(), beta.detach().cuda(), G)
     assert bool(((nc(y0) - pre.detach()).abs() <= pre.detach().abs() * ulp + 1e-5 * float(pre.abs().max())).all())
+    # FPN top-down form: + nearest-2x upsampled coarser level
+    if H % 2 == 0 and W % 2 == 0:
+        coarse = rq(det_tensor((N, C, H // 2, W // 2), 6, -1, 1, bf16=False))
+        ref_u = pre.detach() + F.interpolate(coarse, scale_factor=2, mode="nearest")
+        yu, _ = ops.gn_fwd(nh(z), gamma.detach().cuda(), beta.detach().cuda(), G, 1e-5, nh(coarse), False, ops.ADD_UP2X)
+        assert bool(((nc(yu) - ref_u).abs() <= ref_u.abs() * ulp + 1e-5 * float(ref_u.abs().max())).all())
     # backward: g = cotangent masked by the ReLU (what the consumer's dgrad epilogue hands over)
     cot = rq(det_tensor((N, C, H, W), 5, -1, 1, bf16=False))
     g = rq(cot * (ref.detach() > 0).float())

@@ -74,8 +74,8 @@ SIGNATURES = {
     "tdn_bbox_denormalize": (c_int, [c_void_p, c_void_p, c_i64, c_int, ctypes.POINTER(c_float),
                                      ctypes.POINTER(c_float), c_void_p]),
     "tdn_gn_workspace": (c_i64, [c_int] * 5),
-    "tdn_gn_fwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64,
-                           c_int, c_void_p]),
+    "tdn_gn_fwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_float, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                           c_i64, c_int, c_void_p]),
     "tdn_gn_bwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_i64,
                            c_int, c_void_p]),
     "tdn_collate_images": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32),

@@ -36,8 +36,6 @@ class _ResBlock(nn.Module):
         return [getattr(self, n) for n in self.norm_names]
 
     def hip_spec(self, dtype=torch.bfloat16):
-        if self.use_gn:
-            raise NotImplementedError('GroupNorm residual blocks are not on the HIP path yet (SURVEY §8(f) row 2)')
         norms = self._norms()
         convs = [self.conv1, self.conv2] + ([self.conv3] if self._kind == 'bottleneck' else [])
         us = [HF.prepare_unit(self, 'u%d' % i, c, n, False, dtype) for i, (c, n) in enumerate(zip(convs, norms))]
@@ -186,8 +184,6 @@ class ResNet(nn.Module):
         ``dtype``: torch.bfloat16 / torch.float16 operands; default = ``self.compute_dtype`` (bfloat16)."""
         if dtype is None:
             dtype = getattr(self, 'compute_dtype', torch.bfloat16)
-        if self.use_gn:
-            raise NotImplementedError('ResNet(use_gn=True) is not on the HIP path yet (SURVEY §8(f) row 2)')
         if any(d != 1 for d in self.dilations):
             raise NotImplementedError('dilated ResNet stages are not on the HIP path yet')
         stem = HF.prepare_unit(self, 'stem', self.conv1, getattr(self, self.norm_name), True, dtype)

@@ -123,10 +123,12 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const float* __restr
   }
 }
 
-// [3]: y = relu?(z*a + b (+ addend))
+// [3]: y = relu?(z*a + b (+ addend));  up_w > 0: the addend is the coarser FPN level (H/2 x W/2), read with
+// nearest-neighbour 2x upsampling (fpn.py:98-100), W = 2*up_w
 template <bool F16>
 __global__ void gn_apply_kernel(const bf16_t* __restrict__ z, const float* __restrict__ coef,
-                                const bf16_t* __restrict__ addend, int relu, GnGeom ge, bf16_t* __restrict__ y) {
+                                const bf16_t* __restrict__ addend, int relu, int up_w, GnGeom ge,
+                                bf16_t* __restrict__ y) {
   const int64_t per_n = (int64_t)ge.HW * ge.C8, total = per_n * ge.N;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / per_n);
@@ -137,7 +139,14 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ z, const float* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = elem_to_f32<F16>(zv[e]) * cf[2 * e] + cf[2 * e + 1];
     if (addend) {
-      const bf16x8_t av = *(const bf16x8_t*)(addend + i * 8);
+      int64_t ai = i;
+      if (up_w > 0) {
+        const int W = 2 * up_w;
+        const int64_t pix = (i - (int64_t)n * per_n) / ge.C8;
+        const int h = (int)(pix / W), w = (int)(pix - (int64_t)h * W);
+        ai = (((int64_t)n * (ge.HW / 4)) + (int64_t)(h >> 1) * up_w + (w >> 1)) * ge.C8 + cl;
+      }
+      const bf16x8_t av = *(const bf16x8_t*)(addend + ai * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += elem_to_f32<F16>(av[e]);
     }
@@ -245,10 +254,16 @@ extern "C" int64_t tdn_gn_workspace(int N, int H, int W, int C, int G) {
 }
 
 extern "C" int tdn_gn_fwd(const void* z, const float* gamma, const float* beta, int N, int H, int W, int C, int G,
-                          float eps, const void* addend, int relu, void* y, float* stats, void* workspace,
+                          float eps, const void* addend, int addend_mode, int relu, void* y, float* stats,
+                          void* workspace,
                           int64_t workspace_bytes, int dtype, void* stream) {
   TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(z && gamma && beta && y && stats && workspace, "tdn_gn_fwd: NULL pointer");
+  TDN_CHECK(!addend || addend_mode == TDN_ADD_SAME || addend_mode == TDN_ADD_UP2X,
+            "tdn_gn_fwd: addend_mode %d (TDN_ADD_SAME or TDN_ADD_UP2X)", addend_mode);
+  TDN_CHECK(!(addend && addend_mode == TDN_ADD_UP2X) || (H % 2 == 0 && W % 2 == 0),
+            "tdn_gn_fwd: UP2X addend needs even H, W (got %dx%d)", H, W);
+  const int up_w = (addend && addend_mode == TDN_ADD_UP2X) ? W / 2 : 0;
   GnGeom ge;
   if (make_geom(ge, N, H, W, C, G)) return -1;
   TDN_CHECK(workspace_bytes >= ws_floats(ge) * 4 && ((uintptr_t)workspace & 15) == 0,
@@ -267,7 +282,7 @@ extern "C" int tdn_gn_fwd(const void* z, const float* gamma, const float* beta, 
   int grid = (int)((total + kThreads - 1) / kThreads);
   if (grid > 8192) grid = 8192;
   TDN_LAUNCH_T(gn_apply_kernel, dtype, dim3(grid), dim3(kThreads), st, (const bf16_t*)z, coef, (const bf16_t*)addend,
-               relu, ge, (bf16_t*)y);
+               relu, up_w, ge, (bf16_t*)y);
   TDN_LAUNCH_CHECK();
   return 0;
 }

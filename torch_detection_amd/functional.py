@@ -15,6 +15,7 @@ its gamma/beta still get gradients (``bn_frozen=False``).
 """
 import contextlib
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -59,9 +60,21 @@ class ConvUnit(object):
             if self.Cin % 64 or self.Cout % 64:
                 raise NotImplementedError('HIP conv path needs channel counts that are multiples of 64 '
                                           '(got %d -> %d)' % (self.Cin, self.Cout))
-        if bn is not None and not isinstance(bn, nn.BatchNorm2d):
-            raise NotImplementedError('only BatchNorm2d (eval mode) is folded on the HIP path; GroupNorm is '
-                                      'SURVEY §8(f) row 2')
+        if bn is not None and not isinstance(bn, (nn.BatchNorm2d, nn.GroupNorm)):
+            raise NotImplementedError('only BatchNorm2d (eval mode, folded) and GroupNorm are on the HIP path, got %s'
+                                      % type(bn).__name__)
+        # GroupNorm (layers.py:50-54): per-sample statistics, so nothing folds into the conv — the unit runs as
+        # conv (raw) -> tdn_gn_fwd; ``bn`` keeps holding the norm module either way (its weight / bias are the
+        # second and third parameter of the unit)
+        self.gn = isinstance(bn, nn.GroupNorm)
+        if bn is not None and conv.bias is not None:
+            raise NotImplementedError('a conv with both a bias and a norm layer is not on the HIP path (the reference '
+                                      'builds its normalised convs without bias: layers.py:12-47, fpn.py:26)')
+        if self.gn:
+            C, G = bn.num_channels, bn.num_groups
+            if C != self.Cout or C & (C - 1) or not 64 <= C <= 2048 or not bn.affine:
+                raise NotImplementedError('GroupNorm(%d groups, %d channels, affine=%s) is not on the HIP path '
+                                          '(channels: a power of two in 64..2048)' % (G, C, bn.affine))
         self.key = None
         self.w_fwd = self.w_dgrad = self.scale = self.shift = self.invstd = self.mean = None
         self.sink = None      # optional (dw, d_affine0, d_affine1) views owned by a gradient bucket (dp.py)
@@ -78,7 +91,7 @@ class ConvUnit(object):
     def _version_key(self):
         w = self.conv.weight
         key = [w.data_ptr(), w._version, w.device, self.dtype]
-        if self.bn is not None:
+        if self.bn is not None and not self.gn:
             for t in (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var):
                 key += [t.data_ptr(), t._version]
         elif self.conv.bias is not None:
@@ -87,7 +100,7 @@ class ConvUnit(object):
 
     def refresh(self):
         """(Re)pack weights / fold BN if any source tensor changed since the last call."""
-        if self.bn is not None and self.bn.training:
+        if self.bn is not None and not self.gn and self.bn.training:
             raise NotImplementedError(
                 'BatchNorm2d in training mode (batch statistics) is not on the HIP path; the reference default '
                 'ResNet(bn_eval=True) keeps BN in eval mode (resnet.py:270-276) — call .train()/.eval() on the '
@@ -102,7 +115,9 @@ class ConvUnit(object):
         with torch.no_grad():
             if w.dtype != torch.float32:
                 raise NotImplementedError('parameters must be float32 (bf16 operands are derived on the fly)')
-            if self.bn is not None:
+            if self.gn:
+                self.scale = self.shift = self.invstd = self.mean = None   # gamma / beta are read at launch time
+            elif self.bn is not None:
                 self.scale, self.shift, self.invstd = ops.bn_fold(self.bn.weight, self.bn.bias, self.bn.running_mean,
                                                                   self.bn.running_var, self.bn.eps)
                 self.mean = self.bn.running_mean
@@ -167,14 +182,66 @@ def _as_nchw(t):
     return t.permute(0, 3, 1, 2)
 
 
+# Per-call side storage of the GroupNorm units: the raw conv output z and the (mean, rstd) table of every GN unit of
+# one forward call, consumed by the matching backward call.  The autograd node that is executing (forward or backward)
+# installs its dict here for the duration of the call — thread-local, because backward runs on autograd's thread.
+_gn_tls = threading.local()
+
+
+class gn_scope(object):
+    def __init__(self, store):
+        self.store = store
+
+    def __enter__(self):
+        self.prev = getattr(_gn_tls, 'store', None)
+        _gn_tls.store = self.store
+        return self.store
+
+    def __exit__(self, *exc):
+        _gn_tls.store = self.prev
+        return False
+
+
+def _gn_store(u):
+    st = getattr(_gn_tls, 'store', None)
+    if st is None:
+        raise RuntimeError('GroupNorm unit used outside an autograd node of functional.py')
+    return st
+
+
 def unit_fwd(u, x, addend=None, addend_mode=ADD_NONE, relu=None):
-    return ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode,
-                          u.relu if relu is None else relu)
+    relu = u.relu if relu is None else relu
+    if not u.gn:
+        return ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode, relu)
+    z = ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad)
+    if addend is None:
+        addend_mode = ADD_SAME
+    y, stats = ops.gn_fwd(z, u.bn.weight, u.bn.bias, u.bn.num_groups, u.bn.eps, addend, relu, addend_mode)
+    _gn_store(u)[u] = (z, stats)
+    return y
+
+
+def _gn_dz(u, g):
+    """dL/dz of a GroupNorm unit from g = dL/dy (computed once per backward, shared by its wgrad and dgrad), with
+    the affine gradients written to the unit's sink (dp.py) or to fresh tensors."""
+    st = _gn_store(u)
+    hit = st.get((u, 'dz'))
+    if hit is not None and hit[0] == g.data_ptr():
+        return hit[1]
+    z, stats = st[u]
+    dg = db = None
+    if u.sink is not None:
+        dg, db = u.sink[1], u.sink[2]
+    dz, dg, db = ops.gn_bwd(g, z, stats, u.bn.weight, u.bn.num_groups, dg, db)
+    st[(u, 'dz')] = (g.data_ptr(), dz, dg, db)
+    return dz
 
 
 def unit_dgrad(u, g, in_hw, addend=None, addend_mode=ADD_NONE, mask_src=None):
     if addend is None:
         addend_mode = ADD_NONE
+    if u.gn:
+        g = _gn_dz(u, g)
     return ops.conv2d_dgrad(g, u.w_dgrad, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
 
 
@@ -220,18 +287,24 @@ def unit_wgrad(u, x_in, g, img_hw=None):
     sink = u.sink
     dev = g.device
     dg = db = None
+    gn_affine = None
+    if u.gn:
+        g = _gn_dz(u, g)                       # dL/dz; the affine gradients come from the GroupNorm kernel
+        gn_affine = _gn_store(u)[(u, 'dz')][2:]
     if sink is not None:
         dw, d0, d1 = sink
-        if u.bn is not None:
+        if u.gn:
+            pass                                # dgamma / dbeta were written into the sink by _gn_dz
+        elif u.bn is not None:
             dg, db = d0, d1
         else:
             db = d0
     else:
         # outputs are allocated on the main stream (their consumers live there); only the kernels move
         dw = torch.empty((u.Cout, 3, 7, 7) if u.is_stem else (u.Cout, u.k, u.k, u.Cin), dtype=torch.float32, device=dev)
-        if u.bn is not None:
+        if u.bn is not None and not u.gn:
             dg = torch.empty(u.Cout, dtype=torch.float32, device=dev)
-        if u.bn is not None or u.conv.bias is not None:
+        if (u.bn is not None and not u.gn) or u.conv.bias is not None:
             db = torch.empty(u.Cout, dtype=torch.float32, device=dev)
     side = _side_stream(dev)
     prev = None
@@ -260,6 +333,8 @@ def unit_wgrad(u, x_in, g, img_hw=None):
         u.on_grads(u, side)
     if sink is not None:
         return [None] * len(u.params())
+    if u.gn:
+        return [dw_view, gn_affine[0], gn_affine[1]]
     if u.bn is not None:
         return [dw_view, dg, db]
     if u.conv.bias is not None:
@@ -275,6 +350,12 @@ class ConvUnitFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, unit, x, *params):
+        ctx.gn_saved = {}
+        with gn_scope(ctx.gn_saved):
+            return ConvUnitFunction._forward(ctx, unit, x, *params)
+
+    @staticmethod
+    def _forward(ctx, unit, x, *params):
         xh = ops.to_nhwc_bf16(x, unit.dtype)
         y = unit_fwd(unit, xh)
         ctx.unit, ctx.xh, ctx.y = unit, xh, y
@@ -282,6 +363,11 @@ class ConvUnitFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with gn_scope(ctx.gn_saved):
+            return ConvUnitFunction._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         u = ctx.unit
         g = ops.to_nhwc_bf16(dy, u.dtype)
         if u.relu:
@@ -368,17 +454,33 @@ def _block_bwd(b, saved, g, extra, mask_src, need_dx):
     return dx, grads
 
 
+def _stem_fwd(u, xp, hw):
+    """conv7x7/s2 + norm + ReLU of the stem (resnet.py:254-257): BN folded into the conv epilogue, or GroupNorm."""
+    if not u.gn:
+        return ops.stem_conv_fwd(xp, u.w_fwd, hw, u.scale, u.shift, True)
+    z = ops.stem_conv_fwd(xp, u.w_fwd, hw, None, None, False)
+    s, stats = ops.gn_fwd(z, u.bn.weight, u.bn.bias, u.bn.num_groups, u.bn.eps, None, True)
+    _gn_store(u)[u] = (z, stats)
+    return s
+
+
 class SeqNetFunction(torch.autograd.Function):
     """ResNet.forward (resnet.py:253-268) — or a single residual block — as one autograd node."""
 
     @staticmethod
     def forward(ctx, net, x, *params):
+        ctx.gn_saved = {}
+        with gn_scope(ctx.gn_saved):
+            return SeqNetFunction._forward(ctx, net, x, *params)
+
+    @staticmethod
+    def _forward(ctx, net, x, *params):
         st = {}
         if net.stem is not None and isinstance(x, StagedImages):
             if x.dtype != net.dtype:
                 raise RuntimeError('staged images are %s but the net computes in %s' % (x.dtype, net.dtype))
             xp, (H, W) = x.xp, x.hw
-            s = ops.stem_conv_fwd(xp, net.stem.w_fwd, (H, W), net.stem.scale, net.stem.shift, True)
+            s = _stem_fwd(net.stem, xp, (H, W))
             cur, idx = ops.maxpool3x3s2_fwd(s)
             st.update(xp=xp, s=s, idx=idx, img_hw=(H, W))
         elif net.stem is not None:
@@ -387,7 +489,7 @@ class SeqNetFunction(torch.autograd.Function):
             img = x if x.dtype == torch.float32 else x.float()
             H, W = img.shape[2], img.shape[3]
             xp = ops.stage_image(img, net.dtype)
-            s = ops.stem_conv_fwd(xp, net.stem.w_fwd, (H, W), net.stem.scale, net.stem.shift, True)
+            s = _stem_fwd(net.stem, xp, (H, W))
             cur, idx = ops.maxpool3x3s2_fwd(s)
             st.update(xp=xp, s=s, idx=idx, img_hw=(H, W))
         else:
@@ -407,6 +509,11 @@ class SeqNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
+        with gn_scope(ctx.gn_saved):
+            return SeqNetFunction._backward(ctx, *douts)
+
+    @staticmethod
+    def _backward(ctx, *douts):
         net, st, saved = ctx.net, ctx.st, ctx.saved
         ext = {}
         for bi, d in zip(net.out_blocks, douts):
@@ -469,6 +576,12 @@ class FPNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, *args):
+        ctx.gn_saved = {}
+        with gn_scope(ctx.gn_saved):
+            return FPNFunction._forward(ctx, net, *args)
+
+    @staticmethod
+    def _forward(ctx, net, *args):
         inputs = args[:net.num_ins]
         nlat = len(net.lat)
         xs = [ops.to_nhwc_bf16(inputs[i + net.start_level], net.dtype) for i in range(nlat)]
@@ -502,6 +615,11 @@ class FPNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
+        with gn_scope(ctx.gn_saved):
+            return FPNFunction._backward(ctx, *douts)
+
+    @staticmethod
+    def _backward(ctx, *douts):
         net, xs, lat = ctx.net, ctx.xs, ctx.lat
         nlat = len(net.lat)
         N, C, dev = ctx.out_meta
@@ -576,6 +694,12 @@ class PAPathFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, *args):
+        ctx.gn_saved = {}
+        with gn_scope(ctx.gn_saved):
+            return PAPathFunction._forward(ctx, net, *args)
+
+    @staticmethod
+    def _forward(ctx, net, *args):
         n = len(net.pa1) + 1
         P = [ops.to_nhwc_bf16(t, net.dtype) for t in args[:n]]
         outs, t_saved, s_saved = [P[0]], [], []
@@ -597,6 +721,11 @@ class PAPathFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
+        with gn_scope(ctx.gn_saved):
+            return PAPathFunction._backward(ctx, *douts)
+
+    @staticmethod
+    def _backward(ctx, *douts):
         net, outs, n = ctx.net, ctx.outs, ctx.n
         dev = outs[0].device
         d = [ops.to_nhwc_bf16(t, net.dtype) if t is not None else None for t in douts]

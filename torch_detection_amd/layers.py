@@ -60,9 +60,9 @@ class ConvModule(nn.Module):
     """conv (+bias) [+ BN] [+ ReLU] — the reference's ConvModule (layers.py:57-135).
 
     Same constructor, attributes (``conv``, ``norm``, ``activate``, ``with_norm`` ...) and state_dict keys.
-    Supported on the HIP path: ``activate_last=True`` with ``normalize`` in {None, BN in eval mode} and
-    ``activation`` in {None, 'relu'} — the configurations FPN / PAFPN use.  GroupNorm, 'relu6' and the
-    pre-activation order raise ``NotImplementedError`` in ``forward`` (SURVEY §8(f) row 2).
+    Supported on the HIP path: ``activate_last=True`` with ``normalize`` in {None, BN in eval mode, GroupNorm
+    (``use_gn=True``)} and ``activation`` in {None, 'relu'} — the configurations FPN / PAFPN use.  'relu6' and the
+    pre-activation order raise ``NotImplementedError`` in ``forward``.
     """
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
@@ -104,8 +104,8 @@ class ConvModule(nn.Module):
         """Prepared (cached) fused-conv unit of this module; raises for configurations not on the HIP path."""
         if not self.activate_last:
             raise NotImplementedError('ConvModule(activate_last=False) is not on the HIP path yet')
-        if self.with_norm and (self.use_gn or not isinstance(self.norm, nn.BatchNorm2d)):
-            raise NotImplementedError('ConvModule with GroupNorm is not on the HIP path yet')
+        if self.with_norm and not isinstance(self.norm, (nn.BatchNorm2d, nn.GroupNorm)):
+            raise NotImplementedError('ConvModule norm %s is not on the HIP path' % type(self.norm).__name__)
         if self.with_activation and self.activation != 'relu':
             raise NotImplementedError("ConvModule activation %r is not on the HIP path yet" % self.activation)
         return HF.prepare_unit(self, 'conv', self.conv, self.norm if self.with_norm else None,

@@ -481,7 +481,7 @@ def _gn_ws(N, H, W, C, G, device):
     return _workspace(nbytes, device)
 
 
-def gn_fwd(z, gamma, beta, groups, eps=1e-5, addend=None, relu=False):
+def gn_fwd(z, gamma, beta, groups, eps=1e-5, addend=None, relu=False, addend_mode=ADD_SAME):
     """y = relu?(GroupNorm(z) (+ addend)) on an NHWC raw conv output; returns (y, stats) with stats (N, C, 2) float32
     = per-channel (mean, rstd) for the backward."""
     _chk_act(z, "z")
@@ -490,13 +490,18 @@ def gn_fwd(z, gamma, beta, groups, eps=1e-5, addend=None, relu=False):
     _chk_vec(beta.detach(), "beta", C)
     if addend is not None:
         _chk_act(addend, "addend", C, z.dtype)
-        if addend.shape != z.shape:
-            raise RuntimeError("gn_fwd: addend shape %s != %s" % (tuple(addend.shape), tuple(z.shape)))
+        if addend_mode not in (ADD_SAME, ADD_UP2X):
+            raise ValueError("gn_fwd: addend_mode must be ADD_SAME or ADD_UP2X")
+        exp = (N, H, W, C) if addend_mode == ADD_SAME else (N, H // 2, W // 2, C)
+        if tuple(addend.shape) != exp or (addend_mode == ADD_UP2X and (H % 2 or W % 2)):
+            raise RuntimeError("epilogue addend of spatial size %s does not match output %s (mode %d)" %
+                               (tuple(addend.shape[1:3]), (H, W), addend_mode))
     y = torch.empty_like(z)
     stats = torch.empty(N, C, 2, dtype=torch.float32, device=z.device)
     ws = _gn_ws(N, H, W, C, groups, z.device)
     _lib.check(_lib.load().tdn_gn_fwd(_ptr(z), _ptr(gamma), _ptr(beta), N, H, W, C, int(groups), float(eps),
-                                      _ptr(addend), 1 if relu else 0, _ptr(y), _ptr(stats), _ptr(ws), ws.numel(),
+                                      _ptr(addend), int(addend_mode), 1 if relu else 0, _ptr(y), _ptr(stats), _ptr(ws),
+                                      ws.numel(),
                                       dtype_code(z.dtype), _lib.stream_ptr()), "tdn_gn_fwd")
     return y, stats
 
