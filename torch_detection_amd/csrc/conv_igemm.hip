@@ -97,6 +97,14 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   static_assert(KG == 1 || (MODE == 0 || MODE == 6), "split-K groups: production schedules only");
   static_assert(KG == 1 || BM * BN * 4 <= NSTAGE * STAGE, "partial sums must fit the group's LDS ring");
   constexpr bool EARLY_EPI = FN * FM <= 8;   // small tiles: fetch scale/shift before the K loop (registers to spare)
+  // WIDE: the MFMA rows of channel-fragment i are weight rows  q*4FN + 4i + e  (q = row>>2, e = row&3) of the wave's
+  // channel block instead of 16i + row, so a lane's FN fragments of one pixel are 4FN CONSECUTIVE channels: the
+  // epilogue then moves 8FN contiguous bytes per lane (scale/shift, residual, ReLU mask, store) instead of FN
+  // scattered 8-byte pieces — the store tail of a 192x256 tile was 11 % of the kernel (scripts/trace_gemm.py).
+  // The weight tile gets its own XOR swizzle (swz_w) so that this row pattern still reads LDS conflict-free.
+  constexpr bool WIDE = (BK == 64) && (FN == 2 || FN == 4);
+  constexpr int CPL = 4 * FN;                // channels per lane and pixel
+  constexpr bool OWN_BY_J = (KG == 1) || (FM % KG == 0);   // split-K groups share the epilogue by pixel fragment
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -149,11 +157,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
       }
     }
   }
+  // weight-tile swizzle: 8 distinct values over the even (and the odd) rows of {q*CPL + 4i + e}
+  auto swz_w = [](int row) { return WIDE ? (((row >> 1) & 1) | (((row / CPL) & 3) << 1)) : swz_f<BK>(row); };
   unsigned b_off[B_IT];   // byte offset of this lane's chunk of weight row n (tap 0, k 0); fits 32 bits
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
-    const int n = n0 + it * (RPI * NW) + ld_row;
-    b_off[it] = (unsigned)(((int64_t)n * p.wt_row + src_chunk_el) * 2);
+    const int r = it * (RPI * NW) + ld_row;
+    b_off[it] = (unsigned)(((int64_t)(n0 + r) * p.wt_row + (lchunk ^ swz_w(r)) * 8) * 2);
   }
 
   const int kchunks = p.Ktap / BK;
@@ -214,9 +224,16 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
   const int f_rd = swz_f<BK>(fr);
-  int rd_off[KSUB];
+  int rd_off[KSUB];    // pixel-tile fragment j: sA + j*16*ROWB + rd_off[kk]
+  int rdw_off[KSUB];   // weight-tile fragment i: sB + i*W_STEP + rdw_off[kk]
+  constexpr int W_STEP = (WIDE ? 4 : 16) * ROWB;
+  const int w_row0 = WIDE ? ((fr >> 2) * CPL + (fr & 3)) : fr;
+  const int f_rd_w = WIDE ? (((fr & 3) >> 1) | ((fr >> 2) << 1)) : f_rd;
 #pragma unroll
-  for (int kk = 0; kk < KSUB; ++kk) rd_off[kk] = fr * ROWB + (((kk * 4 + fq) ^ f_rd) * 16);
+  for (int kk = 0; kk < KSUB; ++kk) {
+    rd_off[kk] = fr * ROWB + (((kk * 4 + fq) ^ f_rd) * 16);
+    rdw_off[kk] = w_row0 * ROWB + (((kk * 4 + fq) ^ f_rd_w) * 16);
+  }
 
   f32x4_t acc[FN][FM];
 #pragma unroll
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   auto mfma_substep = [&](const char* sA, const char* sB, int kk) {
     bf16x8_t wf[FN], xf[FM];
 #pragma unroll
-    for (int i = 0; i < FN; ++i) wf[i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[kk]);
+    for (int i = 0; i < FN; ++i) wf[i] = lds_read_b128(sB + i * W_STEP + rdw_off[kk]);
 #pragma unroll
     for (int j = 0; j < FM; ++j) xf[j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[kk]);
 #pragma unroll
@@ -238,13 +255,15 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   };
 
   // epilogue constants; with KG groups, fragment (i, j) is finished by group (i*FM + j) % KG
-  const int ch_base = n0 + wn * WTN + fq * 4;
+  // channel of (fragment i, register e) of this lane: ch_base + i*CH_STEP + e
+  constexpr int CH_STEP = WIDE ? 4 : 16;
+  const int ch_base = n0 + wn * WTN + fq * (WIDE ? CPL : 4);
   f32x4_t sc[FN], sh[FN];
   auto load_affine = [&]() {
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
-      sc[i] = p.scale ? *(const f32x4_t*)(p.scale + ch_base + i * 16) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
-      sh[i] = p.shift ? *(const f32x4_t*)(p.shift + ch_base + i * 16) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      sc[i] = p.scale ? *(const f32x4_t*)(p.scale + ch_base + i * CH_STEP) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+      sh[i] = p.shift ? *(const f32x4_t*)(p.shift + ch_base + i * CH_STEP) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
   };
   if constexpr (EARLY_EPI) load_affine();   // older than every LDS-DMA: the counted vmcnt waits retire them first
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
       } else if constexpr (MODE == 7) {   // ABLATION: MFMA only (fragments never re-read: pure matrix-pipe rate)
         bf16x8_t wf[FN], xf[FM];
 #pragma unroll
-        for (int i = 0; i < FN; ++i) wf[i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[0]);
+        for (int i = 0; i < FN; ++i) wf[i] = lds_read_b128(sB + i * W_STEP + rdw_off[0]);
 #pragma unroll
         for (int j = 0; j < FM; ++j) xf[j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[0]);
         if (t == 0) {
@@ -289,7 +308,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
         for (int kk = 0; kk < KSUB; ++kk) {
 #pragma unroll
           for (int i = 0; i < FN; ++i) {
-            bf16x8_t v = lds_read_b128(sB + i * 16 * ROWB + rd_off[kk]);
+            bf16x8_t v = lds_read_b128(sB + i * W_STEP + rdw_off[kk]);
             asm volatile("" ::"v"(v));
           }
 #pragma unroll
@@ -305,12 +324,12 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
         static_assert(KSUB == 2, "pipelined-fragment schedule assumes BK = 64");
         bf16x8_t wf[2][FN], xf[2][FM];
 #pragma unroll
-        for (int i = 0; i < FN; ++i) wf[0][i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[0]);
+        for (int i = 0; i < FN; ++i) wf[0][i] = lds_read_b128(sB + i * W_STEP + rdw_off[0]);
 #pragma unroll
         for (int j = 0; j < FM; ++j) xf[0][j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[0]);
         stage_load(fill);
 #pragma unroll
-        for (int i = 0; i < FN; ++i) wf[1][i] = lds_read_b128(sB + i * 16 * ROWB + rd_off[1]);
+        for (int i = 0; i < FN; ++i) wf[1][i] = lds_read_b128(sB + i * W_STEP + rdw_off[1]);
 #pragma unroll
         for (int j = 0; j < FM; ++j) xf[1][j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[1]);
 #pragma unroll
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     }
   };
 
-  // ---- epilogue: lane owns channels ch..ch+3 of pixel m for each (i, j) fragment ----
+  // ---- epilogue: per pixel fragment j the lane owns channels ch_base + i*CH_STEP + (0..3), i < FN ----
   if constexpr (!EARLY_EPI) load_affine();
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
@@ -380,38 +399,109 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
       apix = ((int64_t)img * p.addend_h + (oh >> 1)) * p.addend_w + (ow >> 1);
     else if (p.addend_mode == TDN_ADD_SUMPOOL2)
       apix = ((int64_t)img * p.addend_h + 2 * oh) * p.addend_w + 2 * ow;
+    if constexpr (WIDE && OWN_BY_J) {
+      // ---- wide form: this lane's CPL consecutive channels of the pixel in one go ----
+      if (KG > 1 && j % KG != grp) continue;
+      f32x4_t v[FN];
 #pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      if (KG > 1 && (i * FM + j) % KG != grp) continue;
-      const int ch = ch_base + i * 16;
-      f32x4_t v = fragment(i, j) * sc[i] + sh[i];
-      if (p.addend_mode != TDN_ADD_NONE) {
-        const bf16_t* ap = p.addend + apix * p.Cout + ch;
-        const f32x4_t r = load4_f32<F16>(ap);
-        if (p.addend_mode == TDN_ADD_SUMPOOL2) {
-          // sum in a fixed order: (0,0) + (0,1) + (1,0) + (1,1)
-          const f32x4_t r1 = load4_f32<F16>(ap + p.Cout);
-          const f32x4_t r2 = load4_f32<F16>(ap + (int64_t)p.addend_w * p.Cout);
-          const f32x4_t r3 = load4_f32<F16>(ap + (int64_t)(p.addend_w + 1) * p.Cout);
+      for (int i = 0; i < FN; ++i) v[i] = fragment(i, j) * sc[i] + sh[i];
+      auto add_row = [&](const bf16_t* ap) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += ((r[e] + r1[e]) + r2[e]) + r3[e];
-        } else {
-          v += r;
+        for (int h = 0; h < FN / 2; ++h) {
+          const bf16x8_t r = *(const bf16x8_t*)(ap + h * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * h][e] += elem_to_f32<F16>(r[e]);
+            v[2 * h + 1][e] += elem_to_f32<F16>(r[4 + e]);
+          }
         }
+      };
+      if (p.addend_mode == TDN_ADD_SUMPOOL2) {
+        // sum in a fixed order: (0,0) + (0,1) + (1,0) + (1,1)
+        const bf16_t* ap = p.addend + apix * p.Cout + ch_base;
+        const bf16_t* rows[4] = {ap, ap + p.Cout, ap + (int64_t)p.addend_w * p.Cout,
+                                 ap + (int64_t)(p.addend_w + 1) * p.Cout};
+#pragma unroll
+        for (int h = 0; h < FN / 2; ++h) {
+          float acc8[8];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bf16x8_t r = *(const bf16x8_t*)(rows[q] + h * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc8[e] = q == 0 ? elem_to_f32<F16>(r[e]) : acc8[e] + elem_to_f32<F16>(r[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * h][e] += acc8[e]; v[2 * h + 1][e] += acc8[4 + e]; }
+        }
+      } else if (p.addend_mode != TDN_ADD_NONE) {
+        add_row(p.addend + apix * p.Cout + ch_base);
       }
       if (p.relu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
       }
       if (p.mask) {
-        const f32x4_t mk = load4_f32<F16>(p.mask + opix * p.Cout + ch);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (mk[e] > 0.f) ? v[e] : 0.f;
+        for (int h = 0; h < FN / 2; ++h) {
+          const bf16x8_t mk = *(const bf16x8_t*)(p.mask + opix * p.Cout + ch_base + h * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * h][e] = (elem_to_f32<F16>(mk[e]) > 0.f) ? v[2 * h][e] : 0.f;
+            v[2 * h + 1][e] = (elem_to_f32<F16>(mk[4 + e]) > 0.f) ? v[2 * h + 1][e] : 0.f;
+          }
+        }
       }
       if (p.out_f32) {
-        *(f32x4_t*)((float*)p.out + opix * p.Cout + ch) = v;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) *(f32x4_t*)((float*)p.out + opix * p.Cout + ch_base + i * 4) = v[i];
       } else {
-        store4_f32<F16>(p.out + opix * p.Cout + ch, v);
+#pragma unroll
+        for (int h = 0; h < FN / 2; ++h) {
+          bf16x8_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = f32_to_elem<F16>(v[2 * h][e]);
+            o[4 + e] = f32_to_elem<F16>(v[2 * h + 1][e]);
+          }
+          *(bf16x8_t*)(p.out + opix * p.Cout + ch_base + h * 8) = o;
+        }
+      }
+    } else {
+  #pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        if (KG > 1 && (i * FM + j) % KG != grp) continue;
+        const int ch = ch_base + i * CH_STEP;
+        f32x4_t v = fragment(i, j) * sc[i] + sh[i];
+        if (p.addend_mode != TDN_ADD_NONE) {
+          const bf16_t* ap = p.addend + apix * p.Cout + ch;
+          const f32x4_t r = load4_f32<F16>(ap);
+          if (p.addend_mode == TDN_ADD_SUMPOOL2) {
+            // sum in a fixed order: (0,0) + (0,1) + (1,0) + (1,1)
+            const f32x4_t r1 = load4_f32<F16>(ap + p.Cout);
+            const f32x4_t r2 = load4_f32<F16>(ap + (int64_t)p.addend_w * p.Cout);
+            const f32x4_t r3 = load4_f32<F16>(ap + (int64_t)(p.addend_w + 1) * p.Cout);
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += ((r[e] + r1[e]) + r2[e]) + r3[e];
+          } else {
+            v += r;
+          }
+        }
+        if (p.relu) {
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.mask) {
+          const f32x4_t mk = load4_f32<F16>(p.mask + opix * p.Cout + ch);
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (mk[e] > 0.f) ? v[e] : 0.f;
+        }
+        if (p.out_f32) {
+          *(f32x4_t*)((float*)p.out + opix * p.Cout + ch) = v;
+        } else {
+          store4_f32<F16>(p.out + opix * p.Cout + ch, v);
+        }
       }
     }
   }
@@ -470,6 +560,12 @@ static const GemmCfg kCfgs[] = {
     {128, 128, 64, 2, 2, 2, 6, 0, 2},  // 28 2 groups x 4 waves, 128 KB
     {64, 64, 64, 2, 2, 2, 0, 2, 4},  // 29 trace build of 24
     {64, 64, 64, 2, 2, 2, 6, 0, 4},  // 30
+    {192, 256, 64, 2, 4, 2, 4, 2},   // 31 traced loads-only: 8 waves
+    {256, 256, 64, 4, 4, 2, 4, 2},   // 32 traced loads-only: 16 waves
+    {256, 256, 64, 4, 4, 2, 0, 2},   // 33 traced full kernel, 16 waves, MODE 0
+    {256, 256, 64, 4, 4, 2, 6, 2},   // 34 traced full kernel, 16 waves, MODE 6
+    {128, 256, 64, 2, 8, 2, 4, 2},   // 35 traced loads-only: 16 waves, 96 KB
+    {128, 256, 64, 2, 8, 2, 6, 2},   // 36 traced full, 16 waves
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -587,6 +683,12 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
     case 28: return launch_gemm<128, 128, 64, 2, 2, 2, 6, 0, 2>(p, maxM, stream);
     case 29: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 2, 4>(p, maxM, stream);
     case 30: return launch_gemm<64, 64, 64, 2, 2, 2, 6, 0, 4>(p, maxM, stream);
+    case 31: return launch_gemm<192, 256, 64, 2, 4, 2, 4, 2>(p, maxM, stream);
+    case 32: return launch_gemm<256, 256, 64, 4, 4, 2, 4, 2>(p, maxM, stream);
+    case 33: return launch_gemm<256, 256, 64, 4, 4, 2, 0, 2>(p, maxM, stream);
+    case 34: return launch_gemm<256, 256, 64, 4, 4, 2, 6, 2>(p, maxM, stream);
+    case 35: return launch_gemm<128, 256, 64, 2, 8, 2, 4, 2>(p, maxM, stream);
+    case 36: return launch_gemm<128, 256, 64, 2, 8, 2, 6, 2>(p, maxM, stream);
     default: TDN_CHECK(false, "bad GEMM config id"); return -1;
   }
 }
