@@ -69,6 +69,7 @@ def main():
             start = t[:, 0] - t0
             end = t[:, 28] - t0
             setup = t[:, 1] - t[:, 0]
+            kernarg = t[:, 31] - t[:, 0]
             pro = t[:, 2] - t[:, 1]
             first = t[:, 3] - t[:, 2]
             steps = np.diff(t[:, 3:3 + nrec], axis=1) if nrec > 1 else np.zeros((len(t), 1))
@@ -82,9 +83,9 @@ def main():
                   "(=> %.2f GHz if span == event time)" % (name, cfg, us, len(t), T, span, span / us / 1e3))
             print("   start stamp: p50 %d p90 %d max %d | end stamp: p10 %d p50 %d max %d" % (
                 med(start), np.percentile(start, 90), start.max(), np.percentile(end, 10), med(end), end.max()))
-            print("   per workgroup (median cycles): setup %d | prologue issue %d | first data %d | K-step %d "
+            print("   per workgroup (median cycles): kernarg %d | setup %d | prologue issue %d | first data %d | K-step %d "
                   "(p10 %d p90 %d; first 4: %s) | tail(%d steps) %d | epilogue %d | total %d" % (
-                      med(setup), med(pro), med(first), med(steps), np.percentile(steps, 10),
+                      med(kernarg), med(setup), med(pro), med(first), med(steps), np.percentile(steps, 10),
                       np.percentile(steps, 90), np.median(steps[:, :4], axis=0).astype(int).tolist(), T - nrec,
                       med(tail), med(epi), med(total)))
             print("   workgroups per XCC:", np.bincount(xcc, minlength=8).tolist())

@@ -19,7 +19,22 @@ struct GemmClass {
   int oh0, ow0;      // output pixel = (a*so + oh0, b*so + ow0)
   int ntaps;
   int taps[9];       // (dh+64) | (dw+64)<<8 | widx<<16 ; input pixel = (a*sa + dh, b*sa + dw)
+  unsigned mul_hw, shr_hw, mul_w, shr_w;   // exact division of m < 2^31 by Ha*Wa and by Wa: umulhi + shift
 };
+
+// n / d for 0 <= n < 2^31 as umulhi(n, mul) >> shr (mul == 0 encodes d == 1): the row -> (image, y, x) split of every
+// loader row and every epilogue pixel costs 2 multiplies instead of two ~35-instruction integer divisions.
+static void fast_div_init(unsigned d, unsigned* mul, unsigned* shr) {
+  if (d <= 1) { *mul = 0; *shr = 0; return; }
+  unsigned lg = 0;
+  while ((1ull << lg) < d) ++lg;             // ceil(log2(d))
+  const unsigned p = 31 + lg;
+  *mul = (unsigned)(((1ull << p) + d - 1) / d);
+  *shr = p - 32;
+}
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
+  return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
+}
 
 struct GemmParams {
   const bf16_t* in;
@@ -34,6 +49,7 @@ struct GemmParams {
   int sa, so;
   int addend_mode, addend_h, addend_w, relu, out_f32;
   int tiles_n, nwg_pad;
+  unsigned tn_mul, tn_shr;   // fast_div by tiles_n
   int ncls, krot;
   unsigned long long* trace;   // TAG 2 instantiations only: 32 timestamps per workgroup (scripts/trace_gemm.py)
   GemmClass cls[4];
@@ -117,20 +133,36 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
 #pragma unroll
   for (int i = 0; i < 9; ++i) taps_s[i] = c.taps[i];
   const int ntaps = c.ntaps;
+  const int cM = c.M, cWa = c.Wa, HaWa = c.Ha * c.Wa;
+  const unsigned mul_hw = c.mul_hw, shr_hw = c.shr_hw, mul_w = c.mul_w, shr_w = c.shr_w;
+  // every kernel-argument word the set-up needs is requested here, in one batch of scalar loads behind one wait,
+  // instead of trickling in behind six dependent s_waitcnt round trips
+  asm volatile("" ::"s"(ntaps), "s"(cM), "s"(cWa), "s"(HaWa), "s"(mul_hw), "s"(shr_hw), "s"(mul_w), "s"(shr_w),
+               "s"(p.nwg_pad), "s"(p.tiles_n), "s"(p.tn_mul), "s"(p.tn_shr), "s"(p.Hin), "s"(p.Win), "s"(p.Cpix),
+               "s"(p.Ktap), "s"(p.wt_row), "s"(p.sa), "s"(p.in), "s"(p.wt));
+  // tap table in a VGPR (lane i = tap i) and fetched with v_readlane: the loops below index it dynamically, and a
+  // scalar load per K-step would put an s_waitcnt lgkmcnt(0) — which also drains the LDS fragment reads — on the
+  // critical path
+  int tapv = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) tapv = (lane == i) ? taps_s[i] : tapv;
 
   TDN_TRACE(0);
   const int bid = blockIdx.x;
   const int tile = (bid & 7) * (p.nwg_pad >> 3) + (bid >> 3);
-  const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+  const int tile_m = fast_div(tile, p.tn_mul, p.tn_shr), tile_n = tile - tile_m * p.tiles_n;
   const int m0 = tile_m * BM;
-  if (m0 >= c.M) return;
+  if (m0 >= cM) return;
   const int n0 = tile_n * BN;
+  if constexpr (TAG == 2) {   // stamp 31: the first kernel-argument values have arrived (tile index known)
+    asm volatile("" ::"s"(n0), "s"(m0));
+    TDN_TRACE(31);
+  }
 
   // ---- loader thread constants ----
   const int lrow = lane / CH, lchunk = lane % CH;
   const int ld_row = wave * RPI + lrow;                       // + it*RPI*NW
   const int src_chunk_el = (lchunk ^ swz_f<BK>(ld_row)) * 8;  // element offset of the 16B chunk this lane fetches
-  const int HaWa = c.Ha * c.Wa;
   // Per lane and tile row, everything that does not change over the K loop is computed once: the byte address of
   // the row's first channel chunk (tap (0,0)) and a bitmask of the taps that fall inside the image.  Per K-step
   // only a wave-uniform byte offset is added (tap displacement + channel chunk) — the gather costs ~6 VALU per row.
@@ -142,18 +174,18 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     const int m = m0 + it * (RPI * NW) + ld_row;
     a_valid[it] = 0u;
     a_base[it] = zero_src;
-    if (m < c.M) {
-      const int img = m / HaWa;
+    if (m < cM) {
+      const int img = fast_div(m, mul_hw, shr_hw);
       const int rem = m - img * HaWa;
-      const int a = rem / c.Wa;
-      const int b = rem - a * c.Wa;
+      const int a = fast_div(rem, mul_w, shr_w);
+      const int b = rem - a * cWa;
       const int h0 = a * p.sa, w0 = b * p.sa;
       a_base[it] = (const char*)p.in + ((int64_t)((img * p.Hin + h0) * p.Win + w0) * p.Cpix + src_chunk_el) * 2;
-#pragma unroll
-      for (int ti = 0; ti < 9; ++ti) {
-        const int tp = taps_s[ti];
+      for (int ti = 0; ti < ntaps; ++ti) {   // wave-uniform trip count: one pass for a 1x1 conv
+        const int tp = __builtin_amdgcn_readlane(tapv, ti);
         const int h = h0 + (tp & 0xff) - 64, w = w0 + ((tp >> 8) & 0xff) - 64;
-        if (ti < ntaps && ((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win)) a_valid[it] |= 1u << ti;
+        const unsigned ok = (((unsigned)h < (unsigned)p.Hin) & ((unsigned)w < (unsigned)p.Win)) ? 1u : 0u;
+        a_valid[it] |= ok << ti;
       }
     }
   }
@@ -184,13 +216,6 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   if constexpr (KG > 1) {
     for (int i = 0; i < grp; ++i) advance_k();
   }
-  // tap table in a VGPR (lane i = tap i) and fetched with v_readlane: the K loop indexes it dynamically, and a
-  // scalar load per K-step would put an s_waitcnt lgkmcnt(0) — which also drains the LDS fragment reads — on the
-  // critical path
-  int tapv = 0;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) tapv = (lane == i) ? taps_s[i] : tapv;
-
   // issue the LDS-DMA of the next K-step into ring slot s (past the end: dummy loads of the zero page keep the
   // vmcnt bookkeeping uniform)
   auto stage_load = [&](int s) {
@@ -387,11 +412,11 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
     const int m = m0 + wm * WTM + j * 16 + fr;
-    if (m >= c.M) continue;
-    const int img = m / HaWa;
+    if (m >= cM) continue;
+    const int img = fast_div(m, mul_hw, shr_hw);
     const int rem = m - img * HaWa;
-    const int a = rem / c.Wa;
-    const int b = rem - a * c.Wa;
+    const int a = fast_div(rem, mul_w, shr_w);
+    const int b = rem - a * cWa;
     const int oh = a * p.so + c.oh0, ow = b * p.so + c.ow0;
     const int64_t opix = ((int64_t)img * p.Hout + oh) * p.Wout + ow;
     int64_t apix = opix;
@@ -523,6 +548,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
 // host side
 // ---------------------------------------------------------------------------------------------
 static inline int pack_tap(int dh, int dw, int widx) { return (dh + 64) | ((dw + 64) << 8) | (widx << 16); }
+static inline void class_divisors(GemmClass& c) {
+  fast_div_init((unsigned)(c.Ha * c.Wa), &c.mul_hw, &c.shr_hw);
+  fast_div_init((unsigned)c.Wa, &c.mul_w, &c.shr_w);
+}
 
 // Tile configurations. LDS = NSTAGE * (BM + BN) * BK * 2 bytes.  MODE 0: LDS-DMA of the next K-step right after the
 // barrier, fragments read per sub-step; MODE 6: fragment reads software-pipelined under the MFMAs; MODE 3/4/7/8:
@@ -602,6 +631,7 @@ extern "C" int tdn_debug_trace(void* buf, long long bytes) {
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, int MODE = 0, int TAG = 0, int KG = 1, bool F16 = false>
 static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   p.tiles_n = p.Cout / BN;
+  fast_div_init((unsigned)p.tiles_n, &p.tn_mul, &p.tn_shr);
   p.trace = nullptr;
   {
     const char* kr = getenv("TDN_KROT");
@@ -738,6 +768,7 @@ static void build_fwd(GemmParams& p, int N, int H, int W, int Cin, int Cout, int
   c.Ha = Ho; c.Wa = Wo; c.M = N * Ho * Wo; c.oh0 = 0; c.ow0 = 0; c.ntaps = 0;
   for (int kh = 0; kh < k; ++kh)
     for (int kw = 0; kw < k; ++kw) c.taps[c.ntaps++] = pack_tap(kh - pad, kw - pad, kh * k + kw);
+  class_divisors(c);
 }
 
 // Input gradient as a gather: dx[hi][wi] = sum over (kh,kw) with (hi+pad-kh) % s == 0 of g[(hi+pad-kh)/s] * w[kh][kw].
@@ -763,6 +794,7 @@ static int build_dgrad(GemmParams& p, int N, int H, int W, int Cin, int Cout, in
           c.taps[c.ntaps++] = pack_tap((ph + pad - kh) / stride, (pw + pad - kw) / stride, kh * k + kw);
         }
       }
+      class_divisors(c);
       if (c.M > maxM) maxM = c.M;
     }
   return maxM;
@@ -807,6 +839,7 @@ extern "C" int tdn_stem_conv_fwd(const void* xp, const void* w_stem, void* y, in
   GemmClass& c = p.cls[0];
   c.Ha = Ho; c.Wa = Wo; c.M = N * Ho * Wo; c.oh0 = 0; c.ow0 = 0; c.ntaps = 7;
   for (int kh = 0; kh < 7; ++kh) c.taps[kh] = pack_tap(kh, 0, kh);
+  class_divisors(c);
   p.in = (const bf16_t*)xp; p.wt = (const bf16_t*)w_stem; p.out = (bf16_t*)y;
   if (fill_epilogue(p, ep, Ho, Wo)) return -1;
   if (dtype == TDN_F16) return launch_gemm<128, 64, 32, 2, 2, 3, 0, 0, 1, true>(p, c.M, (hipStream_t)stream);

@@ -317,12 +317,15 @@ def unit_wgrad(u, x_in, g, img_hw=None):
         prev = _lib.set_stream_override(side.cuda_stream)
     try:
         if u.is_stem:
-            dw, dg, db = ops.stem_conv_wgrad(x_in, g, u.w_fwd, img_hw, u.scale, u.mean, u.invstd, dw, dg, db)
+            dw, dg, db = ops.stem_conv_wgrad(x_in, g, u.w_fwd, img_hw, u.scale, u.mean, u.invstd, dw, dg, db,
+                                             want_dbeta=db is not None)
             dw_view = dw
         else:
             dw4 = dw.view(u.Cout, u.k, u.k, u.Cin)
+            # every output tensor of this call was allocated above, on the main stream, and stays referenced: the
+            # kernels run on the side stream, so nothing they write may be a temporary of the call
             dw4, dg, db = ops.conv2d_wgrad(x_in, g, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.mean, u.invstd, dw4,
-                                           dg, db)
+                                           dg, db, want_dbeta=db is not None)
             # 1x1: [Cout,1,1,Cin] is byte-identical to the contiguous OIHW parameter -> view, so autograd's
             # layout contract holds and AccumulateGrad does not copy
             dw_view = dw4.view(u.Cout, u.Cin, 1, 1) if u.k == 1 else dw4.permute(0, 3, 1, 2)

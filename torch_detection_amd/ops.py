@@ -152,21 +152,27 @@ def conv2d_dgrad(g, w_dgrad, in_hw, k, stride, pad, addend=None, addend_mode=ADD
 
 
 _ws_cache = {}
+_ws_retired = []   # outgrown workspaces stay referenced: a side stream may still be running kernels that use them
 
 
 def _workspace(nbytes, device):
-    """One grow-only scratch buffer per device; all users are ordered on the current stream."""
+    """One grow-only scratch buffer per (device, launch stream); all users are ordered on that stream."""
     key = (device.index, _lib.stream_ptr())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 
 
 def conv2d_wgrad(x, g, w_fwd, k, stride, pad, scale=None, mean=None, invstd=None, dw=None, dgamma=None,
-                 dbeta=None, beta=0.0):
-    """Weight + affine grads. dw: fp32 [Cout,k,k,Cin] (written, or accumulated when beta=1)."""
+                 dbeta=None, beta=0.0, want_dbeta=True):
+    """Weight + affine grads. dw: fp32 [Cout,k,k,Cin] (written, or accumulated when beta=1).  ``want_dbeta=False``:
+    the per-channel sum of g is not wanted (a conv without bias / with GroupNorm) — nothing is allocated for it.
+    (A temporary here would be written by the finalize kernel on whatever stream the call is routed to and could be
+    recycled by the allocator before that kernel has run.)"""
     _chk_act(x, "x")
     _chk_act(g, "g", None, x.dtype)
     if w_fwd.dtype != x.dtype:
@@ -182,7 +188,7 @@ def conv2d_wgrad(x, g, w_fwd, k, stride, pad, scale=None, mean=None, invstd=None
         dw = torch.empty(Cout, k, k, Cin, dtype=torch.float32, device=dev)
     elif dw.dtype != torch.float32 or dw.numel() != Cout * k * k * Cin:
         raise ValueError("dw has wrong dtype/size")
-    if dbeta is None:
+    if dbeta is None and want_dbeta:
         dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
     if mean is not None and dgamma is None:
         dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
@@ -228,7 +234,7 @@ def stem_conv_fwd(xp, w_stem, hw, scale=None, shift=None, relu=True, out_f32=Fal
 
 
 def stem_conv_wgrad(xp, g, w_stem, hw, scale=None, mean=None, invstd=None, dw=None, dgamma=None, dbeta=None,
-                    beta=0.0):
+                    beta=0.0, want_dbeta=True):
     H, W = hw
     N = xp.shape[0]
     Cout = w_stem.shape[0]
@@ -240,7 +246,7 @@ def stem_conv_wgrad(xp, g, w_stem, hw, scale=None, mean=None, invstd=None, dw=No
     dev = g.device
     if dw is None:
         dw = torch.empty(Cout, 3, 7, 7, dtype=torch.float32, device=dev)
-    if dbeta is None:
+    if dbeta is None and want_dbeta:
         dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
     if mean is not None and dgamma is None:
         dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
