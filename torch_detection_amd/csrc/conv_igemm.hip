@@ -110,7 +110,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   static_assert(A_IT >= 1 && B_IT >= 1 && FM >= 1 && FN >= 1, "tile too small for this wave layout");
   static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "loader does not tile evenly");
   static_assert(NSTAGE >= 2 && LOADS * (NSTAGE - 2) < 64, "vmcnt immediate out of range");
-  static_assert(KG == 1 || (MODE == 0 || MODE == 6), "split-K groups: production schedules only");
+  static_assert(KG == 1 || (MODE == 0 || MODE == 6 || MODE == 9), "split-K groups: production schedules only");
   static_assert(KG == 1 || BM * BN * 4 <= NSTAGE * STAGE, "partial sums must fit the group's LDS ring");
   constexpr bool EARLY_EPI = FN * FM <= 8;   // small tiles: fetch scale/shift before the K loop (registers to spare)
   // WIDE: the MFMA rows of channel-fragment i are weight rows  q*4FN + 4i + e  (q = row>>2, e = row&3) of the wave's
@@ -245,6 +245,37 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     }
   };
 
+  // ABLATION (MODE 9, timing only): the same K-step fetched with plain global_load_dwordx4 into registers and written
+  // to LDS with ds_write_b128 — every load of the step in flight at once, no LDS-DMA
+  auto stage_load_regs = [&](int s) {
+    char* sA = smem + s * STAGE + wave * (RPI * ROWB) + lane * 16;
+    char* sB = sA + A_BYTES;
+    bf16x8_t ra[A_IT], rb[B_IT];
+    const bool live = ld_issued < T;
+    int64_t uoff_a = 0;
+    const char* wt_u = (const char*)p.wt;
+    unsigned bit = 0;
+    if (live) {
+      ld_issued += KG;
+      const int tp = __builtin_amdgcn_readlane(tapv, ld_tap);
+      const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
+      uoff_a = ((int64_t)(dh * p.Win + dw) * p.Cpix + ld_kc * BK) * 2;
+      wt_u = (const char*)p.wt + ((int64_t)widx * p.Ktap + ld_kc * BK) * 2;
+      bit = 1u << ld_tap;
+#pragma unroll
+      for (int i = 0; i < KG; ++i) advance_k();
+    }
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it)
+      ra[it] = *(const bf16x8_t*)((live && (a_valid[it] & bit)) ? a_base[it] + uoff_a : zero_src);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) rb[it] = *(const bf16x8_t*)(live ? wt_u + b_off[it] : zero_src);
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(sA + it * (RPI * NW * ROWB)) = ra[it];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(sB + it * (RPI * NW * ROWB)) = rb[it];
+  };
+
   // ---- fragment reader constants ----
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
@@ -313,6 +344,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
         for (int kk = 0; kk < KSUB; ++kk) mfma_substep(sA, sB, kk);
       } else if constexpr (MODE == 4) {   // ABLATION (timing only, wrong results): loads only, no LDS reads / MFMA
         stage_load(fill);
+      } else if constexpr (MODE == 9) {   // ABLATION: loads only, through registers instead of LDS-DMA
+        stage_load_regs(fill);
       } else if constexpr (MODE == 7) {   // ABLATION: MFMA only (fragments never re-read: pure matrix-pipe rate)
         bf16x8_t wf[FN], xf[FM];
 #pragma unroll
@@ -595,6 +628,16 @@ static const GemmCfg kCfgs[] = {
     {256, 256, 64, 4, 4, 2, 6, 2},   // 34 traced full kernel, 16 waves, MODE 6
     {128, 256, 64, 2, 8, 2, 4, 2},   // 35 traced loads-only: 16 waves, 96 KB
     {128, 256, 64, 2, 8, 2, 6, 2},   // 36 traced full, 16 waves
+    {64, 64, 64, 2, 2, 2, 9, 2},     // 37 traced loads-only through registers (vs 20: LDS-DMA)
+    {64, 128, 64, 2, 2, 2, 9, 2},    // 38
+    {64, 128, 64, 2, 2, 2, 4, 2},    // 39 traced loads-only LDS-DMA, 64x128
+    {192, 256, 64, 2, 4, 2, 9, 2},   // 40 traced loads-only through registers, big tile (vs 31)
+    {64, 128, 64, 2, 4, 2, 6, 2},    // 41 traced 8-wave small tiles
+    {64, 64, 64, 2, 4, 2, 0, 2},     // 42
+    {128, 128, 64, 2, 4, 2, 6, 2},   // 43
+    {64, 128, 64, 2, 4, 2, 6, 0},    // 44 the same, untraced
+    {64, 64, 64, 2, 4, 2, 0, 0},     // 45
+    {128, 128, 64, 2, 4, 2, 6, 0},   // 46 production: 8 waves, 64 KB — mid-size layers with >= 128 such tiles
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -611,7 +654,10 @@ static int choose_cfg(int maxM, int ngemm, int kgemm) {
   // LDS-DMA stream starves (~4 B/clk per loading wave) — recruit a second wave group along K (in-workgroup split-K)
   if ((long)ceil_div(maxM, 64) * (ngemm / 64) <= 512 && kgemm >= 2048) return 25;
   if (ngemm % 128 == 0) {
-    if (maxM >= 100000) return 2;
+    // A K-step costs ~1300-1500 cycles of load latency whatever the tile (scripts/trace_gemm.py), so the 128x128
+    // tile does 2-4x the work per step of the 64-wide ones; with 8 waves (wave tile 64x32) two of them fit a CU.
+    // It wins once there are enough tiles to occupy half the CUs.
+    if ((long)ceil_div(maxM, 128) * (ngemm / 128) >= 128) return 46;
     const long t64 = (long)ceil_div(maxM, 64) * (ngemm / 128);
     return t64 >= 300 ? 1 : 0;
   }
@@ -675,6 +721,7 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
       case 2: return launch_gemm<128, 128, 64, 2, 2, 2, 6, 0, 1, true>(p, maxM, stream);
       case 3: return launch_gemm<192, 256, 64, 2, 4, 2, 6, 0, 1, true>(p, maxM, stream);
       case 25: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 2, true>(p, maxM, stream);
+      case 46: return launch_gemm<128, 128, 64, 2, 4, 2, 6, 0, 1, true>(p, maxM, stream);
       default: TDN_CHECK(false, "GEMM config %d (TDN_GEMM_CFG) has no TDN_F16 build", id); return -1;
     }
   }
@@ -719,6 +766,16 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
     case 34: return launch_gemm<256, 256, 64, 4, 4, 2, 6, 2>(p, maxM, stream);
     case 35: return launch_gemm<128, 256, 64, 2, 8, 2, 4, 2>(p, maxM, stream);
     case 36: return launch_gemm<128, 256, 64, 2, 8, 2, 6, 2>(p, maxM, stream);
+    case 37: return launch_gemm<64, 64, 64, 2, 2, 2, 9, 2>(p, maxM, stream);
+    case 38: return launch_gemm<64, 128, 64, 2, 2, 2, 9, 2>(p, maxM, stream);
+    case 39: return launch_gemm<64, 128, 64, 2, 2, 2, 4, 2>(p, maxM, stream);
+    case 40: return launch_gemm<192, 256, 64, 2, 4, 2, 9, 2>(p, maxM, stream);
+    case 41: return launch_gemm<64, 128, 64, 2, 4, 2, 6, 2>(p, maxM, stream);
+    case 42: return launch_gemm<64, 64, 64, 2, 4, 2, 0, 2>(p, maxM, stream);
+    case 43: return launch_gemm<128, 128, 64, 2, 4, 2, 6, 2>(p, maxM, stream);
+    case 44: return launch_gemm<64, 128, 64, 2, 4, 2, 6, 0>(p, maxM, stream);
+    case 45: return launch_gemm<64, 64, 64, 2, 4, 2, 0, 0>(p, maxM, stream);
+    case 46: return launch_gemm<128, 128, 64, 2, 4, 2, 6, 0>(p, maxM, stream);
     default: TDN_CHECK(false, "bad GEMM config id"); return -1;
   }
 }
