@@ -120,6 +120,27 @@ int tdn_conv2d_wgrad(const void* x, const void* g, const void* w_fwd, const floa
                      int stride, int pad, void* workspace, int64_t workspace_bytes, int dtype,
                      void* stream);
 
+/* ---- grouped convolution (ResNeXt) -----------------------------------
+ * conv3x3_group(..., groups=cardinality) of models/backbone/resnext.py:26-28,82-83: C channels in and out,
+ * `groups` groups.  Computed in block-diagonal form: every 64-channel block of the output multiplies only the same
+ * 64 input channels, with zeros outside the true groups — requires C % 64 == 0 and (C / groups) | 64.
+ *   tdn_pack_gconv_weight: w fp32 logical [C][C/groups][kh][kw] (element strides) ->
+ *       w_fwd [C][kh][kw][64], w_dgrad [C][kh][kw][64] (BN scale folded; may be NULL)
+ *   tdn_gconv2d_fwd / _dgrad: as tdn_conv2d_fwd / _dgrad (same epilogue) on those operands
+ *   tdn_gconv2d_wgrad: dw fp32 [C][kh][kw][C/groups] (= channels_last bytes of the grouped parameter); dgamma / dbeta /
+ *       scale / mean / invstd / beta as in tdn_conv2d_wgrad */
+int tdn_pack_gconv_weight(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int C, int groups,
+                          int kh, int kw, const float* scale, void* w_fwd, void* w_dgrad, int dtype, void* stream);
+int tdn_gconv2d_fwd(const void* x, const void* w_fwd, void* y, int N, int H, int W, int C, int groups, int k,
+                    int stride, int pad, const tdn_epilogue* ep, int dtype, void* stream);
+int tdn_gconv2d_dgrad(const void* g, const void* w_dgrad, void* dx, int N, int H, int W, int C, int groups, int k,
+                      int stride, int pad, const tdn_epilogue* ep, int dtype, void* stream);
+int64_t tdn_gconv2d_wgrad_workspace(int N, int H, int W, int C, int groups, int k, int stride, int pad);
+int tdn_gconv2d_wgrad(const void* x, const void* g, const void* w_fwd, const float* scale, const float* mean,
+                      const float* invstd, float* dw, float* dgamma, float* dbeta, float beta, int N, int H, int W,
+                      int C, int groups, int k, int stride, int pad, void* workspace, int64_t workspace_bytes,
+                      int dtype, void* stream);
+
 /* ---- stem (resnet.py:214-218,254-258) ------------------------------------------ */
 
 /* NCHW image (fp32, arbitrary element strides) -> zero-padded NHWC4 bf16 staging buffer

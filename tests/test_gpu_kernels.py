@@ -278,3 +278,47 @@ def test_bad_shapes_fail_loudly(ops):
         ops.conv2d_fwd(x, w, 1, 1, 0)
     with pytest.raises(ValueError):
         ops.conv2d_fwd(x.float(), w, 1, 1, 0)
+
+
+@pytest.mark.parametrize("case", [
+    # N, H, W, C, groups, k, stride
+    (2, 12, 16, 128, 32, 3, 1),    # 4 channels per group (ResNeXt-50 32x4d layer1)
+    (1, 13, 21, 256, 32, 3, 2),    # 8 per group, stride 2
+    (2, 9, 10, 512, 32, 3, 1),     # 16 per group
+    (1, 8, 8, 1024, 32, 3, 2),     # 32 per group
+    (1, 10, 12, 128, 2, 3, 1),     # 64 per group: one group per block
+])
+def test_grouped_conv(ops, case):
+    """Block-diagonal grouped conv (ResNeXt conv2) forward / dgrad / wgrad + BN affine grads vs F.conv2d(groups=)."""
+    N, H, W, C, G, k, s = case
+    cpg = C // G
+    x = det_tensor((N, C, H, W), 91, -1, 1).requires_grad_(True)
+    w = det_tensor((C, cpg, k, k), 92, -0.3, 0.3).requires_grad_(True)
+    gamma = det_tensor((C,), 93, 0.5, 1.5, bf16=False).requires_grad_(True)
+    beta = det_tensor((C,), 94, -0.5, 0.5, bf16=False).requires_grad_(True)
+    mean = det_tensor((C,), 95, -0.2, 0.2, bf16=False)
+    var = det_tensor((C,), 96, 0.5, 1.5, bf16=False)
+    pre = F.batch_norm(F.conv2d(x, w, None, s, k // 2, 1, G), mean, var, gamma, beta, False, 0.1, 1e-5)
+    ref = F.relu(pre)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma.detach() * invstd
+    shift = beta.detach() - mean * scale
+    wf, wd = ops.pack_gconv_weight(w.detach().cuda(), G, scale.cuda())
+    y = ops.gconv2d_fwd(nhwc(x.detach()), wf, G, k, s, k // 2, scale.cuda(), shift.cuda(), relu=True, out_f32=True)
+    assert max_rel(nchw(y), ref.detach()) <= TOL
+    g = det_tensor(tuple(pre.shape), 97, -1, 1)
+    pre.backward(g)
+    # dgrad: the packed operand folds scale (rounded to bf16): compare against conv_transpose with those weights
+    w_eff = (w.detach() * scale.view(-1, 1, 1, 1)).bfloat16().float()
+    xz = torch.zeros(N, C, H, W, requires_grad=True)
+    F.conv2d(xz, w_eff, None, s, k // 2, 1, G).backward(g)
+    dx = ops.gconv2d_dgrad(nhwc(g), wd, G, (H, W), k, s, k // 2, out_f32=True)
+    assert max_rel(nchw(dx), xz.grad) <= TOL
+    dw, dg, db = ops.gconv2d_wgrad(nhwc(x.detach()), nhwc(g), wf, G, k, s, k // 2, scale.cuda(), mean.cuda(),
+                                   invstd.cuda())
+    assert tuple(dw.shape) == (C, k, k, cpg)
+    assert rel_l2(dw.cpu().permute(0, 3, 1, 2), w.grad) <= TOL
+    assert rel_l2(dg.cpu(), gamma.grad) <= TOL
+    assert rel_l2(db.cpu(), beta.grad) <= TOL
+    with pytest.raises(RuntimeError):
+        ops.pack_gconv_weight(torch.zeros(96, 3, 3, 3, device="cuda"), 32)   # 96 channels: not a multiple of 64

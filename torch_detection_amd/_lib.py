@@ -73,6 +73,12 @@ SIGNATURES = {
     "tdn_bbox_normalize": (c_int, [c_void_p, c_i64, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
     "tdn_bbox_denormalize": (c_int, [c_void_p, c_void_p, c_i64, c_int, ctypes.POINTER(c_float),
                                      ctypes.POINTER(c_float), c_void_p]),
+    "tdn_pack_gconv_weight": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_int, c_void_p]),
+    "tdn_gconv2d_fwd": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
+    "tdn_gconv2d_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
+    "tdn_gconv2d_wgrad_workspace": (c_i64, [c_int] * 8),
+    "tdn_gconv2d_wgrad": (c_int, [c_void_p] * 9 + [c_float] + [c_int] * 8 + [c_void_p, c_i64, c_int, c_void_p]),
     "tdn_gn_workspace": (c_i64, [c_int] * 5),
     "tdn_gn_fwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_float, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                            c_i64, c_int, c_void_p]),

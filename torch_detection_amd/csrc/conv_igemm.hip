@@ -51,6 +51,7 @@ struct GemmParams {
   int tiles_n, nwg_pad;
   unsigned tn_mul, tn_shr;   // fast_div by tiles_n
   int ncls, krot;
+  int grouped;   // block-diagonal grouped conv: the output tile's 64 channels see only the same 64 input channels
   unsigned long long* trace;   // TAG 2 instantiations only: 32 timestamps per workgroup (scripts/trace_gemm.py)
   GemmClass cls[4];
 };
@@ -198,7 +199,11 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     b_off[it] = (unsigned)(((int64_t)(n0 + r) * p.wt_row + (lchunk ^ swz_w(r)) * 8) * 2);
   }
 
-  const int kchunks = p.Ktap / BK;
+  // grouped (ResNeXt) conv in block-diagonal form: weights carry 64 K-columns per tap — the 64 input channels of the
+  // output tile's own channel block (zeros outside the true group) — so the K loop is one chunk per tap, read from
+  // input-channel chunk n0 / 64
+  const int kchunks = p.grouped ? 1 : p.Ktap / BK;
+  const int in_kc0 = p.grouped ? n0 / BK : 0;
   const int T = ntaps * kchunks;
   const int Tg = KG == 1 ? T : (T + KG - 1) / KG;   // K-steps per group (the same for every group: shared barriers)
   // K order: channel chunk outermost, taps innermost.  All taps of a chunk touch the same input lines (shifted by
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
       ld_issued += KG;
       const int tp = __builtin_amdgcn_readlane(tapv, ld_tap);
       const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
-      const int64_t uoff_a = ((int64_t)(dh * p.Win + dw) * p.Cpix + ld_kc * BK) * 2;   // wave-uniform
+      const int64_t uoff_a = ((int64_t)(dh * p.Win + dw) * p.Cpix + (ld_kc + in_kc0) * BK) * 2;   // wave-uniform
       const char* wt_u = (const char*)p.wt + ((int64_t)widx * p.Ktap + ld_kc * BK) * 2;  // wave-uniform
       const unsigned bit = 1u << ld_tap;
 #pragma unroll
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
       ld_issued += KG;
       const int tp = __builtin_amdgcn_readlane(tapv, ld_tap);
       const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
-      uoff_a = ((int64_t)(dh * p.Win + dw) * p.Cpix + ld_kc * BK) * 2;
+      uoff_a = ((int64_t)(dh * p.Win + dw) * p.Cpix + (ld_kc + in_kc0) * BK) * 2;
       wt_u = (const char*)p.wt + ((int64_t)widx * p.Ktap + ld_kc * BK) * 2;
       bit = 1u << ld_tap;
 #pragma unroll
@@ -641,7 +646,8 @@ static const GemmCfg kCfgs[] = {
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
-static int choose_cfg(int maxM, int ngemm, int kgemm) {
+static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0) {
+  if (grouped) return 0;   // block-diagonal grouped conv: one 64-channel block per N tile
   if (const char* env = getenv("TDN_GEMM_CFG")) {
     const int id = atoi(env);
     if (id >= 0 && id < kNumCfgs && ngemm % kCfgs[id].bn == 0) return id;
@@ -714,7 +720,7 @@ static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
 static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype) {
   if (maxM <= 0) return 0;
   if (dtype == TDN_F16) {   // fp16 operands: the production tile set only
-    const int id = choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap);
+    const int id = choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped);
     switch (id) {
       case 0: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 1, true>(p, maxM, stream);
       case 1: return launch_gemm<64, 128, 64, 2, 2, 2, 6, 0, 1, true>(p, maxM, stream);
@@ -725,7 +731,7 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
       default: TDN_CHECK(false, "GEMM config %d (TDN_GEMM_CFG) has no TDN_F16 build", id); return -1;
     }
   }
-  switch (choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap)) {
+  switch (choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped)) {
     case 0: return launch_gemm<64, 64, 64, 2, 2, 2, 0>(p, maxM, stream);
     case 1: return launch_gemm<64, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
     case 2: return launch_gemm<128, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
@@ -820,7 +826,7 @@ static int check_conv_shape(int N, int H, int W, int Cin, int Cout, int k, int s
 static void build_fwd(GemmParams& p, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   p.Hin = H; p.Win = W; p.Cpix = Cin; p.Ktap = Cin; p.wt_row = k * k * Cin;
-  p.Hout = Ho; p.Wout = Wo; p.Cout = Cout; p.sa = stride; p.so = 1; p.ncls = 1;
+  p.Hout = Ho; p.Wout = Wo; p.Cout = Cout; p.sa = stride; p.so = 1; p.ncls = 1; p.grouped = 0;
   GemmClass& c = p.cls[0];
   c.Ha = Ho; c.Wa = Wo; c.M = N * Ho * Wo; c.oh0 = 0; c.ow0 = 0; c.ntaps = 0;
   for (int kh = 0; kh < k; ++kh)
@@ -832,7 +838,7 @@ static void build_fwd(GemmParams& p, int N, int H, int W, int Cin, int Cout, int
 static int build_dgrad(GemmParams& p, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   p.Hin = Ho; p.Win = Wo; p.Cpix = Cout; p.Ktap = Cout; p.wt_row = k * k * Cout;
-  p.Hout = H; p.Wout = W; p.Cout = Cin; p.sa = 1; p.so = stride;
+  p.Hout = H; p.Wout = W; p.Cout = Cin; p.sa = 1; p.so = stride; p.grouped = 0;
   p.ncls = stride * stride;
   int maxM = 0;
   for (int ph = 0; ph < stride; ++ph)
@@ -881,6 +887,41 @@ extern "C" int tdn_conv2d_dgrad(const void* g, const void* w_dgrad, void* dx, in
   return dispatch_gemm(p, maxM, (hipStream_t)stream, dtype);
 }
 
+// Grouped 3x3 / 1x1 conv (ResNeXt, models/backbone/resnext.py:26-28,82-83: conv3x3_group(..., groups=cardinality)) in
+// block-diagonal form: C channels in and out, C % 64 == 0, channels per group dividing 64.  Operands come from
+// tdn_pack_gconv_weight ([C][k][k][64]); every 64-channel output block multiplies only its own 64 input channels.
+static int check_gconv(int C, int groups) {
+  TDN_CHECK(groups > 0 && C % groups == 0, "grouped conv: %d groups do not divide %d channels", groups, C);
+  const int cpg = C / groups;
+  TDN_CHECK(C % 64 == 0 && cpg <= 64 && 64 % cpg == 0,
+            "grouped conv: need C %% 64 == 0 and channels per group dividing 64 (C=%d, groups=%d)", C, groups);
+  return 0;
+}
+
+extern "C" int tdn_gconv2d_fwd(const void* x, const void* w_fwd, void* y, int N, int H, int W, int C, int groups,
+                               int k, int stride, int pad, const tdn_epilogue* ep, int dtype, void* stream) {
+  if (check_conv_shape(N, H, W, C, C, k, stride, pad, dtype) || check_gconv(C, groups)) return -1;
+  TDN_CHECK(x && w_fwd && y, "tdn_gconv2d_fwd: NULL tensor pointer");
+  GemmParams p;
+  build_fwd(p, N, H, W, C, C, k, stride, pad);
+  p.grouped = 1; p.Ktap = 64; p.wt_row = k * k * 64;
+  p.in = (const bf16_t*)x; p.wt = (const bf16_t*)w_fwd; p.out = (bf16_t*)y;
+  if (fill_epilogue(p, ep, p.Hout, p.Wout)) return -1;
+  return dispatch_gemm(p, p.cls[0].M, (hipStream_t)stream, dtype);
+}
+
+extern "C" int tdn_gconv2d_dgrad(const void* g, const void* w_dgrad, void* dx, int N, int H, int W, int C, int groups,
+                                 int k, int stride, int pad, const tdn_epilogue* ep, int dtype, void* stream) {
+  if (check_conv_shape(N, H, W, C, C, k, stride, pad, dtype) || check_gconv(C, groups)) return -1;
+  TDN_CHECK(g && w_dgrad && dx, "tdn_gconv2d_dgrad: NULL tensor pointer");
+  GemmParams p;
+  const int maxM = build_dgrad(p, N, H, W, C, C, k, stride, pad);
+  p.grouped = 1; p.Ktap = 64; p.wt_row = k * k * 64;
+  p.in = (const bf16_t*)g; p.wt = (const bf16_t*)w_dgrad; p.out = (bf16_t*)dx;
+  if (fill_epilogue(p, ep, p.Hout, p.Wout)) return -1;
+  return dispatch_gemm(p, maxM, (hipStream_t)stream, dtype);
+}
+
 // Stem: 7x7 s2 p3 conv on the zero-padded NHWC4 staging buffer xp[N][H+6][W+8][4]. One "tap" per kernel
 // row kh: 8 consecutive pixels x 4 channels = 32 contiguous bf16 (kw = 7 and c = 3 carry zero weights).
 extern "C" int tdn_stem_conv_fwd(const void* xp, const void* w_stem, void* y, int N, int H, int W, int Cout,
@@ -892,7 +933,7 @@ extern "C" int tdn_stem_conv_fwd(const void* xp, const void* w_stem, void* y, in
   GemmParams p;
   const int Ho = H / 2, Wo = W / 2;
   p.Hin = H + 6; p.Win = W + 8; p.Cpix = 4; p.Ktap = 32; p.wt_row = 7 * 32;
-  p.Hout = Ho; p.Wout = Wo; p.Cout = Cout; p.sa = 2; p.so = 1; p.ncls = 1;
+  p.Hout = Ho; p.Wout = Wo; p.Cout = Cout; p.sa = 2; p.so = 1; p.ncls = 1; p.grouped = 0;
   GemmClass& c = p.cls[0];
   c.Ha = Ho; c.Wa = Wo; c.M = N * Ho * Wo; c.oh0 = 0; c.ow0 = 0; c.ntaps = 7;
   for (int kh = 0; kh < 7; ++kh) c.taps[kh] = pack_tap(kh, 0, kh);
@@ -918,7 +959,7 @@ extern "C" int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout,
   int maxM;
   if (kind == 0) { build_fwd(p, N, H, W, Cin, Cout, k, stride, pad); maxM = p.cls[0].M; }
   else maxM = build_dgrad(p, N, H, W, Cin, Cout, k, stride, pad);
-  const GemmCfg& t = kCfgs[choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap)];
+  const GemmCfg& t = kCfgs[choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped)];
   int Mtot = 0, taps_tot = 0;
   for (int i = 0; i < p.ncls; ++i) { Mtot += p.cls[i].M; taps_tot += p.cls[i].ntaps; }
   o[0] = Mtot; o[1] = p.Cout; o[2] = p.cls[0].ntaps * p.Ktap; o[3] = t.bm; o[4] = t.bn; o[5] = t.bk;

@@ -23,6 +23,7 @@ struct WgradParams {
   int ntaps, Ktot;
   int tiles_co, tiles_k;     // tiles over Cout, tiles over (tap, ci)
   int taps[9];               // (dh+64) | (dw+64)<<8
+  int grouped;               // block-diagonal grouped conv: the ci block of a tile is its co block (64 x 64 tiles)
 };
 
 
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
   const int co0 = tile_co * BMW;
   const int kt_per_tap = p.Ktap / BNW;
   const int tap_i = tile_k / kt_per_tap;
-  const int ci0 = (tile_k - tap_i * kt_per_tap) * BNW;
+  const int ci_k = (tile_k - tap_i * kt_per_tap) * BNW;   // column offset inside the tap's K range (slab index)
+  const int ci0 = p.grouped ? co0 : ci_k;                 // channel offset in x
   const int tp = p.taps[tap_i];
   const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64;
   const int m_begin = split * p.Mchunk;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
     const int co = co0 + wm * WTM + i * 16 + fr;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      const int kidx = tap_i * p.Ktap + ci0 + wn * WTN + j * 16 + grp * 4;
+      const int kidx = tap_i * p.Ktap + ci_k + wn * WTN + j * 16 + grp * 4;
       *(f32x4_t*)(slab + (int64_t)co * p.Ktot + kidx) = acc[i][j];
     }
     if (do_colsum && grp == 0) p.colsum[(int64_t)split * p.Cout + co] = acc1[i][0];
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
 // still use the whole block; split-lane partial sums are combined through LDS in lane order (deterministic).
 //   map_mode 0: dw index = co*Ktot + k  ([Cout][kh][kw][Cin] = channels_last view of the OIHW grad)
 //   map_mode 1: stem, k = (kh*8 + kw)*4 + c  ->  dw[co][c][kh][kw] contiguous (pads dropped)
+//   map_mode 4*cpg: grouped conv in block-diagonal form -> dw[co][kh][kw][cpg]
 template <bool F16>
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ slab,
                                                              const float* __restrict__ colsum, int splitk,
@@ -276,6 +279,20 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
         f32x4_t v = s * sc;
         if (beta != 0.f) v += *o * beta;
         *o = v;
+      } else if (map_mode >= 4) {
+        // grouped conv (map_mode = 4 * channels-per-group): k = tap*64 + j is column j of the 64-channel block;
+        // only the columns of co's own group are weight entries: dw[co][tap][j % cpg]
+        const int cpg = map_mode >> 2;
+        const int tap = k >> 6, j0 = k & 63;
+        const int gsel = (co & 63) / cpg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = j0 + e;
+          if (j / cpg != gsel) continue;
+          const int64_t oidx = ((int64_t)co * (Ktot >> 6) + tap) * cpg + (j % cpg);
+          const float v = sc * s[e];
+          dw[oidx] = (beta != 0.f) ? beta * dw[oidx] + v : v;
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 struct WgradPlan { int bmw, bnw, tiles_co, tiles_k, splitk, mchunk, M, Ktot; };
 
-static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps) {
+static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps, bool grouped = false) {
   WgradPlan w;
   // measured (scripts/wgrad_bench.py): 64-wide ci tiles beat 128; 256-wide co tiles (8 waves) win when Cout allows,
   // except for the small-M 3x3 layers where the extra workgroups of the 128-wide tile matter more
@@ -327,6 +344,7 @@ static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps) {
       w.bnw = b;
     }
   }
+  if (grouped) { w.bmw = 64; w.bnw = 64; }   // one 64 x 64 diagonal block per tile
   w.tiles_co = Cout / w.bmw;
   w.tiles_k = ntaps * (Ktap / w.bnw);
   w.M = M;
@@ -448,13 +466,44 @@ extern "C" int tdn_conv2d_wgrad(const void* x, const void* g, const void* w_fwd,
   const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
   const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, Cin, k * k);
   WgradParams p;
-  p.x = (const bf16_t*)x; p.g = (const bf16_t*)g;
+  p.x = (const bf16_t*)x; p.g = (const bf16_t*)g; p.grouped = 0;
   p.Hin = H; p.Win = W; p.Cpix = Cin; p.Ktap = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.sa = stride;
   p.ntaps = k * k;
   for (int kh = 0; kh < k; ++kh)
     for (int kw = 0; kw < k; ++kw) p.taps[kh * k + kw] = (kh - pad + 64) | ((kw - pad + 64) << 8);
   return run_wgrad(p, w, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes, 0,
                    dtype, (hipStream_t)stream);
+}
+
+// Grouped conv weight gradient (see tdn_gconv2d_fwd): per 64-channel block a dense 64 x (taps * 64) product, of which
+// the finalize pass keeps each output channel's own group: dw fp32 [C][k][k][cpg].
+extern "C" int64_t tdn_gconv2d_wgrad_workspace(int N, int H, int W, int C, int groups, int k, int stride, int pad) {
+  const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
+  const WgradPlan w = plan_wgrad(N * Ho * Wo, C, 64, k * k, true);
+  return wgrad_ws_bytes(w, C);
+}
+
+extern "C" int tdn_gconv2d_wgrad(const void* x, const void* g, const void* w_fwd, const float* scale,
+                                 const float* mean, const float* invstd, float* dw, float* dgamma, float* dbeta,
+                                 float beta, int N, int H, int W, int C, int groups, int k, int stride, int pad,
+                                 void* workspace, int64_t workspace_bytes, int dtype, void* stream) {
+  TDN_CHECK(dtype == TDN_BF16 || dtype == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", dtype);
+  TDN_CHECK(x && g && w_fwd && dw && workspace, "tdn_gconv2d_wgrad: NULL pointer");
+  TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported", k);
+  TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported", stride);
+  TDN_CHECK(pad == k / 2, "pad %d not supported for k=%d", pad, k);
+  TDN_CHECK(groups > 0 && C % groups == 0 && C % 64 == 0 && (C / groups) <= 64 && 64 % (C / groups) == 0,
+            "grouped conv: need C %% 64 == 0 and channels per group dividing 64 (C=%d, groups=%d)", C, groups);
+  const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
+  const WgradPlan w = plan_wgrad(N * Ho * Wo, C, 64, k * k, true);
+  WgradParams p;
+  p.x = (const bf16_t*)x; p.g = (const bf16_t*)g; p.grouped = 1;
+  p.Hin = H; p.Win = W; p.Cpix = C; p.Ktap = 64; p.Ho = Ho; p.Wo = Wo; p.Cout = C; p.sa = stride;
+  p.ntaps = k * k;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) p.taps[kh * k + kw] = (kh - pad + 64) | ((kw - pad + 64) << 8);
+  return run_wgrad(p, w, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes,
+                   4 * (C / groups), dtype, (hipStream_t)stream);
 }
 
 extern "C" int64_t tdn_stem_conv_wgrad_workspace(int N, int H, int W, int Cout) {
@@ -472,7 +521,7 @@ extern "C" int tdn_stem_conv_wgrad(const void* xp, const void* g, const void* w_
   const int Ho = H / 2, Wo = W / 2;
   const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, 32, 7);
   WgradParams p;
-  p.x = (const bf16_t*)xp; p.g = (const bf16_t*)g;
+  p.x = (const bf16_t*)xp; p.g = (const bf16_t*)g; p.grouped = 0;
   p.Hin = H + 6; p.Win = W + 8; p.Cpix = 4; p.Ktap = 32; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.sa = 2;
   p.ntaps = 7;
   for (int kh = 0; kh < 7; ++kh) p.taps[kh] = (kh + 64) | ((0 + 64) << 8);

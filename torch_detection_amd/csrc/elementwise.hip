@@ -82,6 +82,49 @@ extern "C" int tdn_pack_conv_weight(const float* w, int64_t s_o, int64_t s_i, in
   return 0;
 }
 
+// Grouped conv weight [C][cpg][kh][kw] (resnext.py:26-28,82-83) -> block-diagonal operands [C][kh][kw][64]:
+//   w_fwd[co][tap][j]   = w[co][j % cpg][tap]                 if input slot j (channel 64*(co/64) + j) is in co's group
+//   w_dgrad[ci][tap][j] = scale[co'] * w[co'][ci % cpg][tap]  with co' = 64*(ci/64) + j, if co' is in ci's group
+// zeros elsewhere.
+template <bool F16>
+__global__ void pack_gconv_kernel(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int C, int cpg,
+                                  int kh, int kw, const float* scale, bf16_t* w_fwd, bf16_t* w_dgrad) {
+  const int64_t total = (int64_t)C * kh * kw * 64;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 63);
+    int64_t r = i >> 6;
+    const int x = (int)(r % kw);
+    r /= kw;
+    const int y = (int)(r % kh);
+    const int c = (int)(r / kh);   // row channel: output channel for w_fwd, input channel for w_dgrad
+    const bool same = (j / cpg) == ((c & 63) / cpg);
+    float vf = 0.f, vd = 0.f;
+    if (same) {
+      const float wf = w[c * s_o + (j % cpg) * s_i + y * s_h + x * s_w];
+      vf = wf;
+      const int co = (c & ~63) + j;   // the output channel this dgrad entry multiplies
+      const float wd = w[co * s_o + (c % cpg) * s_i + y * s_h + x * s_w];
+      vd = elem_to_f32<F16>(f32_to_elem<F16>(wd)) * (scale ? scale[co] : 1.f);
+    }
+    w_fwd[i] = f32_to_elem<F16>(vf);
+    if (w_dgrad) w_dgrad[i] = f32_to_elem<F16>(vd);
+  }
+}
+
+extern "C" int tdn_pack_gconv_weight(const float* w, int64_t s_o, int64_t s_i, int64_t s_h, int64_t s_w, int C,
+                                     int groups, int kh, int kw, const float* scale, void* w_fwd, void* w_dgrad,
+                                     int dtype, void* stream) {
+  TDN_CHECK_DTYPE(dtype);
+  TDN_CHECK(w && w_fwd, "tdn_pack_gconv_weight: NULL pointer");
+  TDN_CHECK(groups > 0 && C % groups == 0 && C % 64 == 0 && (C / groups) <= 64 && 64 % (C / groups) == 0,
+            "grouped conv: need C %% 64 == 0 and channels per group dividing 64 (C=%d, groups=%d)", C, groups);
+  const int64_t total = (int64_t)C * kh * kw * 64;
+  TDN_LAUNCH_T(pack_gconv_kernel, dtype, dim3(grid_for(total, 256)), dim3(256), (hipStream_t)stream, w, s_o, s_i, s_h,
+               s_w, C, C / groups, kh, kw, scale, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
 template <bool F16>
 __global__ void pack_stem_kernel(const float* w, int Cout, bf16_t* w_fwd) {
   const int total = Cout * 7 * 8 * 4;

@@ -533,3 +533,91 @@ def gn_bwd(g, z, stats, gamma, groups, dgamma=None, dbeta=None, accumulate=False
                                       _ptr(dgamma), _ptr(dbeta), 1.0 if accumulate else 0.0, _ptr(ws), ws.numel(),
                                       dtype_code(z.dtype), _lib.stream_ptr()), "tdn_gn_bwd")
     return dz, dgamma, dbeta
+
+
+# ---- grouped convolution (ResNeXt) ---------------------------------------------------------------------
+def pack_gconv_weight(w, groups, scale=None, want_dgrad=True, dtype=BF16):
+    """Grouped conv weight fp32 [C][C/groups][kh][kw] (any strides) -> block-diagonal operands
+    (w_fwd [C][kh][kw][64], w_dgrad [C][kh][kw][64] with the BN scale folded)."""
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_cuda or w.dim() != 4:
+        raise ValueError("weight must be a CUDA float32 4-D tensor")
+    C, cpg, kh, kw = w.shape
+    if cpg * groups != C:
+        raise ValueError("grouped weight %s does not match %d groups" % (tuple(w.shape), groups))
+    _chk_vec(scale, "scale", C)
+    w_fwd = torch.empty(C, kh, kw, 64, dtype=dtype, device=w.device)
+    w_dg = torch.empty(C, kh, kw, 64, dtype=dtype, device=w.device) if want_dgrad else None
+    s = w.stride()
+    _lib.check(_lib.load().tdn_pack_gconv_weight(_ptr(w), s[0], s[1], s[2], s[3], C, int(groups), kh, kw, _ptr(scale),
+                                                 _ptr(w_fwd), _ptr(w_dg), dtype_code(dtype), _lib.stream_ptr()),
+               "tdn_pack_gconv_weight")
+    return w_fwd, w_dg
+
+
+def _chk_gw(wp, name, C, k, dtype):
+    if wp.dtype != dtype or tuple(wp.shape) != (C, k, k, 64) or not wp.is_contiguous():
+        raise ValueError("%s must be %s [C,k,k,64] contiguous (pack_gconv_weight), got %s %s" %
+                         (name, dtype, wp.dtype, tuple(wp.shape)))
+
+
+def gconv2d_fwd(x, w_fwd, groups, k, stride, pad, scale=None, shift=None, addend=None, addend_mode=ADD_NONE,
+                relu=False, out_f32=False):
+    _chk_act(x, "x")
+    N, H, W, C = x.shape
+    _chk_gw(w_fwd, "w_fwd", C, k, x.dtype)
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    y = torch.empty(N, Ho, Wo, C, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    ep = make_epilogue(C, Ho, Wo, scale, shift, addend, addend_mode, relu, None, N, out_f32, x.dtype)
+    _lib.check(_lib.load().tdn_gconv2d_fwd(_ptr(x), _ptr(w_fwd), _ptr(y), N, H, W, C, int(groups), k, stride, pad,
+                                           ctypes.byref(ep), dtype_code(x.dtype), _lib.stream_ptr()),
+               "tdn_gconv2d_fwd")
+    return y
+
+
+def gconv2d_dgrad(g, w_dgrad, groups, in_hw, k, stride, pad, addend=None, addend_mode=ADD_NONE, mask_src=None,
+                  out_f32=False):
+    _chk_act(g, "g")
+    N, Ho, Wo, C = g.shape
+    H, W = in_hw
+    _chk_gw(w_dgrad, "w_dgrad", C, k, g.dtype)
+    if (Ho, Wo) != (conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)):
+        raise RuntimeError("dgrad: g spatial size %s inconsistent with input %s" % ((Ho, Wo), (H, W)))
+    dx = torch.empty(N, H, W, C, dtype=torch.float32 if out_f32 else g.dtype, device=g.device)
+    ep = make_epilogue(C, H, W, None, None, addend, addend_mode, False, mask_src, N, out_f32, g.dtype)
+    _lib.check(_lib.load().tdn_gconv2d_dgrad(_ptr(g), _ptr(w_dgrad), _ptr(dx), N, H, W, C, int(groups), k, stride,
+                                             pad, ctypes.byref(ep), dtype_code(g.dtype), _lib.stream_ptr()),
+               "tdn_gconv2d_dgrad")
+    return dx
+
+
+def gconv2d_wgrad(x, g, w_fwd, groups, k, stride, pad, scale=None, mean=None, invstd=None, dw=None, dgamma=None,
+                  dbeta=None, beta=0.0, want_dbeta=True):
+    """dw fp32 [C,k,k,C/groups] (+ BN affine grads like conv2d_wgrad)."""
+    _chk_act(x, "x")
+    _chk_act(g, "g", None, x.dtype)
+    N, H, W, C = x.shape
+    _chk_gw(w_fwd, "w_fwd", C, k, x.dtype)
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    if tuple(g.shape) != (N, Ho, Wo, C):
+        raise RuntimeError("gconv wgrad: inconsistent shapes x=%s g=%s" % (tuple(x.shape), tuple(g.shape)))
+    cpg = C // groups
+    dev = x.device
+    if dw is None:
+        dw = torch.empty(C, k, k, cpg, dtype=torch.float32, device=dev)
+    elif dw.dtype != torch.float32 or dw.numel() != C * k * k * cpg:
+        raise ValueError("dw has wrong dtype/size")
+    if dbeta is None and want_dbeta:
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    if mean is not None and dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    for t, n in ((scale, "scale"), (mean, "mean"), (invstd, "invstd"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _chk_vec(t, n, C)
+    lib = _lib.load()
+    nbytes = lib.tdn_gconv2d_wgrad_workspace(N, H, W, C, int(groups), k, stride, pad)
+    ws = _workspace(nbytes, dev)
+    _lib.check(lib.tdn_gconv2d_wgrad(_ptr(x), _ptr(g), _ptr(w_fwd), _ptr(scale), _ptr(mean), _ptr(invstd), _ptr(dw),
+                                     _ptr(dgamma), _ptr(dbeta), float(beta), N, H, W, C, int(groups), k, stride, pad,
+                                     _ptr(ws), ws.numel(), dtype_code(x.dtype), _lib.stream_ptr()),
+               "tdn_gconv2d_wgrad")
+    return dw, dgamma, dbeta
