@@ -331,6 +331,60 @@ def main():
                           "state_keys": manifest_of(m), "out_shapes": [list(t.shape) for t in ref]}
     np.savez_compressed(os.path.join(GOLD, "gn.npz"), **gn)
 
+    # ---- ResNeXt: grouped-conv bottlenecks fwd + all grads, ResNeXt-50 32x4d forward ------
+    import importlib
+    ref_resnext = importlib.import_module("models.backbone.resnext")
+    RefResNeXt = BACKBONES.module_dict["ResNeXt"]
+    rx = {}
+    xcases = {
+        "x32x4d_s1_down": (64, 64, 4, 32, 1, (2, 10, 12)),      # layer1.0: 128 ch, 4 per group
+        "x32x4d_s2_down": (256, 128, 4, 32, 2, (2, 9, 12)),     # layer2.0: 256 ch, 8 per group, stride 2
+        "x32x16d_s1_nodown": (256, 64, 16, 32, 1, (1, 6, 8)),   # D = 16: 512 ch, 16 per group, identity residual
+    }
+    for ci, (name, (inpl, planes, bw, card, stride, (n, h, w))) in enumerate(sorted(xcases.items())):
+        blk = ref_resnext._make_resX_layer(ref_resnext.ResNeXtBottleneck, inpl, planes, 1, bw, card, stride=stride)[0]
+        sd = fill_state_dict(blk.state_dict(), 1800 + ci)
+        blk.load_state_dict(sd)
+        blk.eval()
+        x = det_tensor((n, inpl, h, w), 1810 + ci, -1.0, 1.0).requires_grad_(True)
+        y = blk(x)
+        dy = det_tensor(tuple(y.shape), 1820 + ci, -1.0, 1.0)
+        y.backward(dy)
+        ps = {("b." + k): v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k)
+              for k, v in sd.items()}
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = O._resnext_bottleneck(x2, ps, "b", stride, card, blk.downsample is not None)
+        y2.backward(dy)
+        assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad), "oracle != reference (ResNeXt %s)" % name
+        for k, p in blk.named_parameters():
+            assert torch.equal(ps["b." + k].grad, p.grad), "oracle grad != reference (ResNeXt %s %s)" % (name, k)
+        rx["blk/" + name + "/y"] = y.detach().numpy()
+        rx["blk/" + name + "/dx"] = x.grad.numpy()
+        for k, p in blk.named_parameters():
+            rx["blk/" + name + "/grad/" + k] = p.grad.numpy()
+        man.setdefault("resnext_blocks", {})[name] = {
+            "inplanes": inpl, "planes": planes, "base_width": bw, "cardinality": card, "stride": stride,
+            "x_shape": [n, inpl, h, w], "state_seed": 1800 + ci, "x_seed": 1810 + ci, "dy_seed": 1820 + ci,
+            "state_keys": manifest_of(blk)}
+    m = RefResNeXt(50, 4, 32)
+    sd = fill_state_dict(m.state_dict(), 1900)
+    m.load_state_dict(sd)
+    m.train()
+    x = det_tensor((1, 3, 64, 96), 1901, -2.0, 2.0)
+    with torch.no_grad():
+        ref = m(x)
+        mine = O.resnext_forward(sd, x, 50, 32)
+    for a_, b_ in zip(ref, mine):
+        assert torch.equal(a_, b_), "oracle != reference (ResNeXt-50 forward)"
+    for i, t in enumerate(ref):
+        rx["x50/c%d" % (i + 2)] = t.numpy()
+    man["resnext50_32x4d"] = {"input": {"shape": [1, 3, 64, 96], "seed": 1901, "lo": -2.0, "hi": 2.0},
+                              "state_seed": 1900, "state_keys": manifest_of(m),
+                              "out_shapes": [list(t.shape) for t in ref],
+                              "all_bn_eval_after_train": all(not x_.training for x_ in m.modules()
+                                                             if isinstance(x_, torch.nn.BatchNorm2d))}
+    np.savez_compressed(os.path.join(GOLD, "resnext.npz"), **rx)
+
     # ---- image batch staging: normalize -> flip -> pad to /32 -> CHW -> collate ------------
     from datasets.utils.image import img_flip, img_normalize, img_pad_size_divisor
     from datasets.utils import DataContainer

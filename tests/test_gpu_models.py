@@ -280,3 +280,44 @@ def test_groupnorm_variants_vs_golden(T, manifest, golden_dir):
     assert max(errs) <= 2e-2, errs
     torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])    # stem GN + max-pool adjoint path runs
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+def test_resnext_vs_golden(T, manifest, golden_dir):
+    """ResNeXt grouped-conv bottlenecks (fwd + all grads) and ResNeXt-50 32x4d forward + a backward pass, against
+    golden vectors from the reference (tests/golden/resnext.npz).  Bounds as for the ResNet blocks."""
+    from torch_detection_amd.backbone.resnext import ResNeXtBottleneck, _make_resX_layer
+    gold = np.load(os.path.join(golden_dir, "resnext.npz"))
+    for name, meta in sorted(manifest["resnext_blocks"].items()):
+        blk = _make_resX_layer(ResNeXtBottleneck, meta["inplanes"], meta["planes"], 1, meta["base_width"],
+                               meta["cardinality"], stride=meta["stride"])[0]
+        blk.load_state_dict(fill_state_dict(blk.state_dict(), meta["state_seed"]))
+        blk.cuda().eval()
+        x = det_tensor(tuple(meta["x_shape"]), meta["x_seed"], -1, 1).cuda().requires_grad_(True)
+        y = blk(x)
+        assert y.shape == gold["blk/%s/y" % name].shape and y.dtype == torch.bfloat16
+        y.backward(det_tensor(tuple(y.shape), meta["dy_seed"], -1, 1).cuda().to(y.dtype))
+        ey = rel_l2(_f32(y), torch.from_numpy(gold["blk/%s/y" % name]))
+        edx = rel_l2(_f32(x.grad), torch.from_numpy(gold["blk/%s/dx" % name]))
+        eg = {}
+        for k, p in blk.named_parameters():
+            g = torch.from_numpy(gold["blk/%s/grad/%s" % (name, k)])
+            assert p.grad is not None and p.grad.shape == g.shape, (name, k)
+            eg[k] = rel_l2(_f32(p.grad), g)
+        _record("resnext_block/" + name, {"y": ey, "dx": edx, "grad_max": max(eg.values())})
+        assert ey <= 6e-3, (name, ey)
+        assert edx <= 1e-1, (name, edx)
+        assert max(eg.values()) <= 1e-1, (name, eg)
+    meta = manifest["resnext50_32x4d"]
+    m = T.BACKBONES.module_dict["ResNeXt"](50, 4, 32)
+    m.load_state_dict(fill_state_dict(m.state_dict(), meta["state_seed"]))
+    m.cuda().train()
+    i = meta["input"]
+    outs = m(det_tensor(tuple(i["shape"]), i["seed"], i["lo"], i["hi"]).cuda())
+    assert [list(o.shape) for o in outs] == meta["out_shapes"]
+    errs = [rel_l2(_f32(o), torch.from_numpy(gold["x50/c%d" % (k + 2)])) for k, o in enumerate(outs)]
+    _record("resnext50_32x4d", errs)
+    assert max(errs) <= 2e-2, errs
+    torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    w = m.layer1[0].conv2.weight
+    assert w.grad.shape == w.shape and w.grad.stride() == w.stride()     # layout contract: no copy in AccumulateGrad

@@ -250,3 +250,45 @@ def test_groupnorm_oracle_and_manifests_vs_reference_golden(manifest, golden_dir
         ref = O.resnet_forward(sd, det_tensor(tuple(i["shape"]), i["seed"], i["lo"], i["hi"]), 18)
     for k, t in enumerate(ref):
         assert np.array_equal(t.numpy(), gold["r18/c%d" % (k + 2)])
+
+
+def test_resnext_oracle_and_manifests_vs_reference_golden(manifest, golden_dir):
+    """ResNeXt: the oracle's grouped-conv bottleneck (fwd + all grads) and ResNeXt-50 32x4d
+    forward equal the reference bit for bit; the drop-in classes carry the reference's state_dict keys and the
+    registry hands out ``ResNeXt``."""
+    import torch_detection_amd as T
+    from oracle import torch_ref as O
+    from torch_detection_amd.backbone.resnext import ResNeXtBottleneck, _make_resX_layer
+    torch.set_num_threads(4)
+    gold = np.load(os.path.join(golden_dir, "resnext.npz"))
+
+    def keys(m):
+        return [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+
+    assert "ResNeXt" in T.BACKBONES.module_dict and "ResNeXt" in manifest["registry"]["backbone"]
+    for name, meta in sorted(manifest["resnext_blocks"].items()):
+        blk = _make_resX_layer(ResNeXtBottleneck, meta["inplanes"], meta["planes"], 1, meta["base_width"],
+                               meta["cardinality"], stride=meta["stride"])[0]
+        assert keys(blk) == meta["state_keys"], name
+        sd = fill_state_dict(blk.state_dict(), meta["state_seed"])
+        ps = {("b." + k): v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+        x = det_tensor(tuple(meta["x_shape"]), meta["x_seed"], -1, 1).requires_grad_(True)
+        y = O._resnext_bottleneck(x, ps, "b", meta["stride"], meta["cardinality"],
+                                  any(k.startswith("downsample") for k in sd))
+        y.backward(det_tensor(tuple(y.shape), meta["dy_seed"], -1, 1))
+        assert np.array_equal(y.detach().numpy(), gold["blk/%s/y" % name]), name
+        assert np.array_equal(x.grad.numpy(), gold["blk/%s/dx" % name]), name
+        for k, p in blk.named_parameters():
+            assert np.array_equal(ps["b." + k].grad.numpy(), gold["blk/%s/grad/%s" % (name, k)]), (name, k)
+    meta = manifest["resnext50_32x4d"]
+    m = T.ResNeXt(50, 4, 32)
+    assert keys(m) == meta["state_keys"]
+    m.train()
+    assert all(not x.training for x in m.modules() if isinstance(x, torch.nn.BatchNorm2d)) == \
+        meta["all_bn_eval_after_train"]
+    sd = fill_state_dict(m.state_dict(), meta["state_seed"])
+    i = meta["input"]
+    with torch.no_grad():
+        ref = O.resnext_forward(sd, det_tensor(tuple(i["shape"]), i["seed"], i["lo"], i["hi"]), 50, 32)
+    for k, t in enumerate(ref):
+        assert np.array_equal(t.numpy(), gold["x50/c%d" % (k + 2)])

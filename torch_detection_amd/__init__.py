@@ -13,7 +13,8 @@ from .layers import (ConvModule, conv1x1_group, conv3x3_group, conv7x7_group, ge
 from .inits import (bias_init_with_prob, constant_init, kaiming_init, normal_init, uniform_init,  # noqa: F401
                     xavier_init)
 from .checkpoint import load_checkpoint, load_state_dict, save_checkpoint  # noqa: F401
-from .backbone import BasicBlock, Bottleneck, ResNet  # noqa: F401
+from .backbone import (BasicBlock, Bottleneck, ResNet, ResNeXt, ResNeXtBasicBlock,  # noqa: F401
+                       ResNeXtBottleneck)
 from .necks import FPN, PAFPN  # noqa: F401
 from .staging import ImageTransforms, StagedImages  # noqa: F401
 from .box import (AnchorGenerator, bbox_denormalize, bbox_normalize, bbox_overlaps, nms,  # noqa: F401

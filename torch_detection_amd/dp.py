@@ -142,7 +142,7 @@ def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True, dty
         if u.is_stem:
             wview = views[0].view(w.shape)
         else:
-            wview = views[0].view(w.shape) if u.k == 1 else views[0].view(u.Cout, u.k, u.k, u.Cin).permute(0, 3, 1, 2)
+            wview = views[0].view(w.shape) if u.k == 1 else views[0].view(u.Cout, u.k, u.k, u.Cin // u.groups).permute(0, 3, 1, 2)
         w.grad = wview
         for p, v in zip(ps[1:], views[1:]):
             p.grad = v.view(p.shape)

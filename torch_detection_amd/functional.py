@@ -44,8 +44,14 @@ class ConvUnit(object):
         self.k, self.stride, self.pad = kh, conv.stride[0], conv.padding[0]
         self.Cin, self.Cout = conv.in_channels, conv.out_channels
         self.is_stem = (kh == 7)
+        # grouped conv (ResNeXt conv2, resnext.py:26-28,82-83): block-diagonal form over 64-channel blocks
+        self.groups = conv.groups
         if conv.groups != 1:
-            raise NotImplementedError('grouped convolution is not on the HIP path (ResNeXt: SURVEY §2 row 10)')
+            cpg = conv.in_channels // conv.groups
+            if conv.in_channels != conv.out_channels or conv.in_channels % 64 or cpg > 64 or 64 % cpg or kh == 7:
+                raise NotImplementedError('grouped convolution %d -> %d with %d groups is not on the HIP path (needs '
+                                          'equal channel counts, a multiple of 64, channels per group dividing 64)'
+                                          % (conv.in_channels, conv.out_channels, conv.groups))
         if conv.dilation != (1, 1):
             raise NotImplementedError('dilated convolution is not on the HIP path yet')
         if kh != kw or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
@@ -127,6 +133,8 @@ class ConvUnit(object):
             if self.is_stem:
                 self.w_fwd = ops.pack_stem_weight(w.detach().contiguous(), self.dtype)
                 self.w_dgrad = None
+            elif self.groups > 1:
+                self.w_fwd, self.w_dgrad = ops.pack_gconv_weight(w, self.groups, self.scale, True, self.dtype)
             else:
                 self.w_fwd, self.w_dgrad = ops.pack_conv_weight(w, self.scale, True, self.dtype)
         self.key = key
@@ -212,8 +220,14 @@ def _gn_store(u):
 def unit_fwd(u, x, addend=None, addend_mode=ADD_NONE, relu=None):
     relu = u.relu if relu is None else relu
     if not u.gn:
+        if u.groups > 1:
+            return ops.gconv2d_fwd(x, u.w_fwd, u.groups, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode,
+                                   relu)
         return ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode, relu)
-    z = ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad)
+    if u.groups > 1:
+        z = ops.gconv2d_fwd(x, u.w_fwd, u.groups, u.k, u.stride, u.pad)
+    else:
+        z = ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad)
     if addend is None:
         addend_mode = ADD_SAME
     y, stats = ops.gn_fwd(z, u.bn.weight, u.bn.bias, u.bn.num_groups, u.bn.eps, addend, relu, addend_mode)
@@ -242,6 +256,8 @@ def unit_dgrad(u, g, in_hw, addend=None, addend_mode=ADD_NONE, mask_src=None):
         addend_mode = ADD_NONE
     if u.gn:
         g = _gn_dz(u, g)
+    if u.groups > 1:
+        return ops.gconv2d_dgrad(g, u.w_dgrad, u.groups, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
     return ops.conv2d_dgrad(g, u.w_dgrad, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
 
 
@@ -301,7 +317,8 @@ def unit_wgrad(u, x_in, g, img_hw=None):
             db = d0
     else:
         # outputs are allocated on the main stream (their consumers live there); only the kernels move
-        dw = torch.empty((u.Cout, 3, 7, 7) if u.is_stem else (u.Cout, u.k, u.k, u.Cin), dtype=torch.float32, device=dev)
+        dw = torch.empty((u.Cout, 3, 7, 7) if u.is_stem else (u.Cout, u.k, u.k, u.Cin // u.groups),
+                         dtype=torch.float32, device=dev)
         if u.bn is not None and not u.gn:
             dg = torch.empty(u.Cout, dtype=torch.float32, device=dev)
         if (u.bn is not None and not u.gn) or u.conv.bias is not None:
@@ -321,14 +338,18 @@ def unit_wgrad(u, x_in, g, img_hw=None):
                                              want_dbeta=db is not None)
             dw_view = dw
         else:
-            dw4 = dw.view(u.Cout, u.k, u.k, u.Cin)
+            dw4 = dw.view(u.Cout, u.k, u.k, u.Cin // u.groups)
             # every output tensor of this call was allocated above, on the main stream, and stays referenced: the
             # kernels run on the side stream, so nothing they write may be a temporary of the call
-            dw4, dg, db = ops.conv2d_wgrad(x_in, g, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.mean, u.invstd, dw4,
-                                           dg, db, want_dbeta=db is not None)
+            if u.groups > 1:
+                dw4, dg, db = ops.gconv2d_wgrad(x_in, g, u.w_fwd, u.groups, u.k, u.stride, u.pad, u.scale, u.mean,
+                                                u.invstd, dw4, dg, db, want_dbeta=db is not None)
+            else:
+                dw4, dg, db = ops.conv2d_wgrad(x_in, g, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.mean, u.invstd,
+                                               dw4, dg, db, want_dbeta=db is not None)
             # 1x1: [Cout,1,1,Cin] is byte-identical to the contiguous OIHW parameter -> view, so autograd's
             # layout contract holds and AccumulateGrad does not copy
-            dw_view = dw4.view(u.Cout, u.Cin, 1, 1) if u.k == 1 else dw4.permute(0, 3, 1, 2)
+            dw_view = dw4.view(u.Cout, u.Cin // u.groups, 1, 1) if u.k == 1 else dw4.permute(0, 3, 1, 2)
     finally:
         if side is not None:
             _lib.set_stream_override(prev)

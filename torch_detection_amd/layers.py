@@ -18,7 +18,7 @@ from . import functional as HF
 
 
 def _channels_last_(conv):
-    if conv.weight.shape[2] * conv.weight.shape[3] > 1 and conv.weight.shape[1] % 64 == 0:
+    if conv.weight.shape[2] * conv.weight.shape[3] > 1 and (conv.weight.shape[1] % 64 == 0 or conv.groups > 1):
         conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
     return conv
 
