@@ -69,7 +69,8 @@ struct GemmParams {
 
 template <int BK>
 __device__ __forceinline__ int swz_f(int row) {
-  if constexpr (BK == 64) return (row >> 1) & 7;
+  if constexpr (BK == 128) return row & 15;        // 256-byte rows: every row starts at bank 0, 16 chunks
+  else if constexpr (BK == 64) return (row >> 1) & 7;
   else return (4 - ((row >> 2) & 3)) & 3;
 }
 
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   static_assert(A_IT >= 1 && B_IT >= 1 && FM >= 1 && FN >= 1, "tile too small for this wave layout");
   static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "loader does not tile evenly");
   static_assert(NSTAGE >= 2 && LOADS * (NSTAGE - 2) < 64, "vmcnt immediate out of range");
-  static_assert(KG == 1 || (MODE == 0 || MODE == 6 || MODE == 9), "split-K groups: production schedules only");
+  static_assert(KG == 1 || (MODE == 0 || MODE == 6 || MODE == 9 || MODE == 10), "split-K groups: production schedules only");
   static_assert(KG == 1 || BM * BN * 4 <= NSTAGE * STAGE, "partial sums must fit the group's LDS ring");
   constexpr bool EARLY_EPI = FN * FM <= 8;   // small tiles: fetch scale/shift before the K loop (registers to spare)
   // WIDE: the MFMA rows of channel-fragment i are weight rows  q*4FN + 4i + e  (q = row>>2, e = row&3) of the wave's
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   // epilogue then moves 8FN contiguous bytes per lane (scale/shift, residual, ReLU mask, store) instead of FN
   // scattered 8-byte pieces — the store tail of a 192x256 tile was 11 % of the kernel (scripts/trace_gemm.py).
   // The weight tile gets its own XOR swizzle (swz_w) so that this row pattern still reads LDS conflict-free.
-  constexpr bool WIDE = (BK == 64) && (FN == 2 || FN == 4);
+  constexpr bool WIDE = (BK >= 64) && (FN == 2 || FN == 4);
   constexpr int CPL = 4 * FN;                // channels per lane and pixel
   constexpr bool OWN_BY_J = (KG == 1) || (FM % KG == 0);   // split-K groups share the epilogue by pixel fragment
 
@@ -191,7 +192,11 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     }
   }
   // weight-tile swizzle: 8 distinct values over the even (and the odd) rows of {q*CPL + 4i + e}
-  auto swz_w = [](int row) { return WIDE ? (((row >> 1) & 1) | (((row / CPL) & 3) << 1)) : swz_f<BK>(row); };
+  auto swz_w = [](int row) {
+    if constexpr (!WIDE) return swz_f<BK>(row);
+    else if constexpr (BK == 128) return (row & 3) | (((row / CPL) & 3) << 2);   // 16 distinct values over (q, e)
+    else return ((row >> 1) & 1) | (((row / CPL) & 3) << 1);
+  };
   unsigned b_off[B_IT];   // byte offset of this lane's chunk of weight row n (tap 0, k 0); fits 32 bits
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
@@ -250,6 +255,46 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     }
   };
 
+  // ABLATION (MODE 10, timing only): the same K-step fetched with buffer_load_dwordx4 ... offen lds — a descriptor
+  // per operand whose base carries the wave-uniform part (tap displacement, channel chunk), a 32-bit per-lane offset,
+  // and the hardware range check instead of the zero page for out-of-image taps
+  unsigned a_off32[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it)
+    a_off32[it] = a_valid[it] ? (unsigned)(a_base[it] - (const char*)p.in) : 0x80000000u;
+  auto stage_load_buf = [&](int s) {
+    char* sA = smem + s * STAGE + wave * (RPI * ROWB);
+    char* sB = sA + A_BYTES;
+    const bool live = ld_issued < T;
+    const char* a_u = (const char*)p.in;
+    const char* wt_u = (const char*)p.wt;
+    unsigned bit = 0;
+    if (live) {
+      ld_issued += KG;
+      const int tp = __builtin_amdgcn_readlane(tapv, ld_tap);
+      const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
+      a_u += ((int64_t)(dh * p.Win + dw) * p.Cpix + (ld_kc + in_kc0) * BK) * 2;
+      wt_u += ((int64_t)widx * p.Ktap + ld_kc * BK) * 2;
+      bit = 1u << ld_tap;
+#pragma unroll
+      for (int i = 0; i < KG; ++i) advance_k();
+    }
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer builtins exist for the device target only
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a_u, 0, live ? 0x7fffffff : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)wt_u, 0, live ? 0x7fffffff : 0, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const unsigned off = (a_valid[it] & bit) ? a_off32[it] : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (TDN_LDS void*)(sA + it * (RPI * NW * ROWB)), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (TDN_LDS void*)(sB + it * (RPI * NW * ROWB)), 16, b_off[it], 0, 0, 0);
+#else
+    (void)sA; (void)sB; (void)a_u; (void)wt_u; (void)bit;
+#endif
+  };
+
   // ABLATION (MODE 9, timing only): the same K-step fetched with plain global_load_dwordx4 into registers and written
   // to LDS with ds_write_b128 — every load of the step in flight at once, no LDS-DMA
   auto stage_load_regs = [&](int s) {
@@ -289,7 +334,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   int rdw_off[KSUB];   // weight-tile fragment i: sB + i*W_STEP + rdw_off[kk]
   constexpr int W_STEP = (WIDE ? 4 : 16) * ROWB;
   const int w_row0 = WIDE ? ((fr >> 2) * CPL + (fr & 3)) : fr;
-  const int f_rd_w = WIDE ? (((fr & 3) >> 1) | ((fr >> 2) << 1)) : f_rd;
+  const int f_rd_w = !WIDE ? f_rd : (BK == 128 ? ((fr & 3) | ((fr >> 2) << 2)) : (((fr & 3) >> 1) | ((fr >> 2) << 1)));
 #pragma unroll
   for (int kk = 0; kk < KSUB; ++kk) {
     rd_off[kk] = fr * ROWB + (((kk * 4 + fq) ^ f_rd) * 16);
@@ -351,6 +396,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
         stage_load(fill);
       } else if constexpr (MODE == 9) {   // ABLATION: loads only, through registers instead of LDS-DMA
         stage_load_regs(fill);
+      } else if constexpr (MODE == 10) {  // ABLATION: loads only, buffer_load ... lds
+        stage_load_buf(fill);
       } else if constexpr (MODE == 7) {   // ABLATION: MFMA only (fragments never re-read: pure matrix-pipe rate)
         bf16x8_t wf[FN], xf[FM];
 #pragma unroll
@@ -643,14 +690,22 @@ static const GemmCfg kCfgs[] = {
     {64, 128, 64, 2, 4, 2, 6, 0},    // 44 the same, untraced
     {64, 64, 64, 2, 4, 2, 0, 0},     // 45
     {128, 128, 64, 2, 4, 2, 6, 0},   // 46 production: 8 waves, 64 KB — mid-size layers with >= 128 such tiles
+    {64, 64, 64, 2, 2, 2, 10, 2},    // 47 traced loads-only, buffer_load ... lds (vs 20)
+    {64, 64, 64, 2, 2, 4, 10, 2},    // 48 (vs 21)
+    {192, 256, 64, 2, 4, 2, 10, 2},  // 49 (vs 31)
+    {64, 64, 128, 2, 2, 2, 0, 0},    // 50 BK = 128: twice the work per ~1300-cycle K-step
+    {64, 128, 128, 2, 2, 2, 0, 0},   // 51
+    {128, 128, 128, 2, 4, 2, 0, 0},  // 52
+    {64, 64, 128, 2, 2, 2, 0, 2},    // 53 traced 50
+    {64, 128, 128, 2, 4, 2, 0, 0},   // 54 8 waves
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
-static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0) {
+static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0, int ktap = 64) {
   if (grouped) return 0;   // block-diagonal grouped conv: one 64-channel block per N tile
   if (const char* env = getenv("TDN_GEMM_CFG")) {
     const int id = atoi(env);
-    if (id >= 0 && id < kNumCfgs && ngemm % kCfgs[id].bn == 0) return id;
+    if (id >= 0 && id < kNumCfgs && ngemm % kCfgs[id].bn == 0 && ktap % kCfgs[id].bk == 0) return id;
   }
   // Measured on MI355X over the R50-FPN shapes (scripts/conv_bench.py; profiles/convbench_*.log): several small
   // co-resident workgroups per CU (64-pixel tiles, 2-deep ring, 32-48 KB LDS) beat one large deeply pipelined
@@ -720,7 +775,7 @@ static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
 static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype) {
   if (maxM <= 0) return 0;
   if (dtype == TDN_F16) {   // fp16 operands: the production tile set only
-    const int id = choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped);
+    const int id = choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped, p.Ktap);
     switch (id) {
       case 0: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 1, true>(p, maxM, stream);
       case 1: return launch_gemm<64, 128, 64, 2, 2, 2, 6, 0, 1, true>(p, maxM, stream);
@@ -731,7 +786,7 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
       default: TDN_CHECK(false, "GEMM config %d (TDN_GEMM_CFG) has no TDN_F16 build", id); return -1;
     }
   }
-  switch (choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped)) {
+  switch (choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped, p.Ktap)) {
     case 0: return launch_gemm<64, 64, 64, 2, 2, 2, 0>(p, maxM, stream);
     case 1: return launch_gemm<64, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
     case 2: return launch_gemm<128, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
@@ -782,6 +837,14 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
     case 44: return launch_gemm<64, 128, 64, 2, 4, 2, 6, 0>(p, maxM, stream);
     case 45: return launch_gemm<64, 64, 64, 2, 4, 2, 0, 0>(p, maxM, stream);
     case 46: return launch_gemm<128, 128, 64, 2, 4, 2, 6, 0>(p, maxM, stream);
+    case 47: return launch_gemm<64, 64, 64, 2, 2, 2, 10, 2>(p, maxM, stream);
+    case 48: return launch_gemm<64, 64, 64, 2, 2, 4, 10, 2>(p, maxM, stream);
+    case 49: return launch_gemm<192, 256, 64, 2, 4, 2, 10, 2>(p, maxM, stream);
+    case 50: return launch_gemm<64, 64, 128, 2, 2, 2, 0, 0>(p, maxM, stream);
+    case 51: return launch_gemm<64, 128, 128, 2, 2, 2, 0, 0>(p, maxM, stream);
+    case 52: return launch_gemm<128, 128, 128, 2, 4, 2, 0, 0>(p, maxM, stream);
+    case 53: return launch_gemm<64, 64, 128, 2, 2, 2, 0, 2>(p, maxM, stream);
+    case 54: return launch_gemm<64, 128, 128, 2, 4, 2, 0, 0>(p, maxM, stream);
     default: TDN_CHECK(false, "bad GEMM config id"); return -1;
   }
 }
@@ -959,7 +1022,7 @@ extern "C" int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout,
   int maxM;
   if (kind == 0) { build_fwd(p, N, H, W, Cin, Cout, k, stride, pad); maxM = p.cls[0].M; }
   else maxM = build_dgrad(p, N, H, W, Cin, Cout, k, stride, pad);
-  const GemmCfg& t = kCfgs[choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped)];
+  const GemmCfg& t = kCfgs[choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped, p.Ktap)];
   int Mtot = 0, taps_tot = 0;
   for (int i = 0; i < p.ncls; ++i) { Mtot += p.cls[i].M; taps_tot += p.cls[i].ntaps; }
   o[0] = Mtot; o[1] = p.Cout; o[2] = p.cls[0].ntaps * p.Ktap; o[3] = t.bm; o[4] = t.bn; o[5] = t.bk;
