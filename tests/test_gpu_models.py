@@ -321,3 +321,37 @@ def test_resnext_vs_golden(T, manifest, golden_dir):
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
     w = m.layer1[0].conv2.weight
     assert w.grad.shape == w.shape and w.grad.stride() == w.stride()     # layout contract: no copy in AccumulateGrad
+
+
+def test_graphed_step_matches_eager(T):
+    """GraphedStep: one captured forward+backward replayed == the eager step, bit for bit (static tensors)."""
+    m = T.ResNet(18).cuda().train()
+    m.init_weights()
+    neck = T.FPN([64, 128, 256, 512], 256, 5).cuda()
+    neck.init_weights()
+    x = det_tensor((2, 3, 64, 96), 9, -1, 1).cuda()
+    with torch.no_grad():   # shape probe only: an autograd graph built on the default stream must not outlive this
+        outs = neck(m(x))   # line (its AccumulateGrad nodes would tie the captured backward to the default stream)
+    cots = [det_tensor(tuple(o.shape), 20 + i, -1, 1).cuda().to(o.dtype) for i, o in enumerate(outs)]
+    del outs
+    params = list(m.parameters()) + list(neck.parameters())
+    held = {}
+
+    def step():
+        for p in params:
+            p.grad = None
+        o = neck(m(x))
+        torch.autograd.backward(o, cots)
+        held["outs"] = o
+
+    gs = T.GraphedStep(step)     # capture first (warm-up runs on a side stream), eager reference afterwards
+    assert gs.captured, gs.error
+    for _ in range(2):
+        gs()
+    torch.cuda.synchronize()
+    got_o = [t.clone() for t in held["outs"]]
+    got_g = [p.grad.clone() for p in params]
+    step()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(held["outs"], got_o))
+    assert all(torch.equal(p.grad, g) for p, g in zip(params, got_g))

@@ -134,7 +134,7 @@ def stream_ptr():
 def set_stream_override(raw_stream):
     """Route this thread's kernel launches to ``raw_stream`` (int) until reset with ``None``.  Cheaper than
     ``with torch.cuda.stream(...)`` (no allocator / current-stream switching); allocations stay on the current
-    PyTorch stream, so callers must order memory reuse themselves (``record_stream``)."""
+    PyTorch stream, so callers must order memory reuse themselves (functional._side_refs)."""
     prev = getattr(_tls, "stream", None)
     _tls.stream = raw_stream
     return prev

@@ -288,13 +288,21 @@ def _side_stream(device):
     return pool[_side_rr[0]]
 
 
+# Tensors read by side-stream kernels are kept referenced here until the main stream has joined the side streams:
+# their memory then cannot be handed out again before those kernels have run.  (Not ``Tensor.record_stream``: the
+# allocator's deferred-free events do not mix with hipGraph capture — capture_end crashed with them.)
+_side_refs = {}
+
+
 def join_side_stream(device):
     """Make the current stream wait for the side streams' weight-gradient kernels (end of a backward pass)."""
-    pool = _side_streams.get((device.index, torch._C._cuda_getCurrentRawStream(device.index)))
+    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index))
+    pool = _side_streams.get(key)
     if pool:
         cur = torch.cuda.current_stream(device)
         for st in pool:
             cur.wait_stream(st)
+    _side_refs.pop(key, None)
 
 
 def unit_wgrad(u, x_in, g, img_hw=None):
@@ -329,8 +337,8 @@ def unit_wgrad(u, x_in, g, img_hw=None):
         ev = torch.cuda.Event()
         ev.record()               # g (and everything before it) is ready on the main stream
         side.wait_event(ev)
-        for t in (x_in, g):       # keep their memory from being recycled while the side stream still reads it
-            t.record_stream(side)
+        # keep the operands' memory from being recycled while the side stream still reads it (see _side_refs)
+        _side_refs.setdefault((dev.index, torch._C._cuda_getCurrentRawStream(dev.index)), []).extend((x_in, g))
         prev = _lib.set_stream_override(side.cuda_stream)
     try:
         if u.is_stem:
