@@ -256,6 +256,12 @@ def main():
         else:
             mode = "eager (graph capture failed)"
 
+    if graph is None:
+        # eager launches: run autograd's backward on this thread — the hand-off to the engine's device thread costs
+        # ~1.5 ms of the ~7.4 ms it takes to enqueue a step (scripts/host_profile.py), and the step is host-bound
+        torch.autograd.set_multithreading_enabled(False)
+        mode += ", single-threaded autograd"
+
     def run_step():
         if graph is not None:
             graph()

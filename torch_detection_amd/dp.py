@@ -58,21 +58,24 @@ class GradReducer(object):
     def reset(self):
         self._pending = [b[2] for b in self.buckets]
         self._works = []
-        self._producers = [[] for _ in self.buckets]   # streams that wrote into each bucket this step
+        self._producers = [{} for _ in self.buckets]   # raw stream -> stream that wrote into each bucket this step
 
     def mark_ready(self, slot, stream=None):
         """Slot's gradient has been enqueued on ``stream`` (default: the current stream); launch its bucket's
         all-reduce if complete."""
-        b = self.bucket_of[slot]
-        self._pending[b] -= 1
-        if self.use_streams:
-            st = stream if stream is not None else torch.cuda.current_stream(self.device)
-            if all(st != q for q in self._producers[b]):
-                self._producers[b].append(st)
+        self.mark_ready_n(self.bucket_of[slot], 1, stream)
+
+    def mark_ready_n(self, b, count, stream=None):
+        """``count`` slots of bucket ``b`` have been enqueued on ``stream`` (one call per conv unit from the backward
+        schedule: a unit's weight / affine gradients are consecutive slots, normally of one bucket)."""
+        self._pending[b] -= count
+        if self.use_streams and stream is not None:
+            self._producers[b][stream.cuda_stream] = stream
         if self._pending[b] == 0:
             self._launch(b)
         elif self._pending[b] < 0:
-            raise RuntimeError('GradReducer: slot %d marked ready twice in one step (call reset()/finish())' % slot)
+            raise RuntimeError('GradReducer: bucket %d got more gradients than it has slots in one step '
+                               '(call reset()/finish())' % b)
 
     def _launch(self, b):
         start, end, _ = self.buckets[b]
@@ -83,7 +86,7 @@ class GradReducer(object):
             # the bucket's gradients were produced on several streams (the weight-gradient kernels rotate over a
             # pool of side streams): the comm stream waits for every one of them — and for the current stream, which
             # covers buckets flushed from finish() and gradients written by the main stream
-            for st in self._producers[b] + [torch.cuda.current_stream(self.device)]:
+            for st in list(self._producers[b].values()) + [torch.cuda.current_stream(self.device)]:
                 ev = torch.cuda.Event()
                 ev.record(st)
                 self.comm_stream.wait_event(ev)
@@ -149,9 +152,14 @@ def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True, dty
         u.sink = (views[0].view(w.shape) if u.is_stem else views[0], views[1] if len(ps) > 1 else None,
                   views[2] if len(ps) > 2 else None)
 
-        def _cb(unit, stream=None, _slots=slots, _red=red):
-            for s in _slots:
-                _red.mark_ready(s, stream)
+        per_bucket = {}
+        for s_ in slots:
+            per_bucket[red.bucket_of[s_]] = per_bucket.get(red.bucket_of[s_], 0) + 1
+        per_bucket = tuple(per_bucket.items())
+
+        def _cb(unit, stream=None, _pb=per_bucket, _red=red):
+            for b_, n_ in _pb:
+                _red.mark_ready_n(b_, n_, stream)
         u.on_grads = _cb
     return red
 

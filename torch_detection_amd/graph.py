@@ -16,6 +16,7 @@ output shapes under ``torch.no_grad()``): its AccumulateGrad nodes would make th
 the default stream, which a capture cannot contain — hipStreamEndCapture crashes on it.
 """
 import sys
+import time
 
 import torch
 
@@ -24,10 +25,13 @@ class GraphedStep(object):
     """Captures ``fn`` (after ``warmup`` eager calls on a side stream) and replays it.  ``captured`` tells whether the
     graph exists; if capture raised, the error is printed once and every call runs ``fn`` eagerly."""
 
-    def __init__(self, fn, warmup=3, verbose=True):
+    def __init__(self, fn, warmup=3, verbose=True, settle=None):
         self.fn = fn
         self.graph = None
         self.error = None
+        if settle is None:
+            import torch.distributed as dist
+            settle = 0.5 if (dist.is_available() and dist.is_initialized()) else 0.0
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -36,8 +40,15 @@ class GraphedStep(object):
                     fn()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if settle > 0:
+                # under torch.distributed the process group's watchdog thread polls the events of the warm-up's
+                # collectives (every ~100 ms) until it has seen them complete; an event query that lands inside the
+                # capture window is an illegal call during capture and aborts the process — let the watchdog drain
+                time.sleep(settle)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: other threads (that watchdog, the allocator's helpers) are not policed during the capture;
+            # the launches autograd's device thread makes into the capturing streams are captured either way
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
             self.graph = g
         except Exception as e:  # noqa: BLE001 - fall back loudly, never silently
