@@ -30,7 +30,7 @@ MFMA_PEAK_TFLOPS = 2500.0          # bf16 dense, MI355X_MICROARCH.md
 DOM = dict(Cin=256, Cout=256, k=3, stride=1, H=200, W=336)   # neck.fpn_convs.0: 79.27 GFLOP / image
 # HBM bytes of ONE launch of that kernel at batch 2 from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes,
 # FETCH_SIZE doubled per MI355X_MICROARCH.md): filled in from profiles/ (None until measured)
-DOM_TRAFFIC_BYTES = 1.743e8  # 2*FETCH_SIZE(51488 KiB) + WRITE_SIZE(67200 KiB); algorithmic 1.388e8
+DOM_TRAFFIC_BYTES = 1.742e8  # 2*FETCH_SIZE(51456 KiB) + WRITE_SIZE(67200 KiB); algorithmic 1.388e8
 DOM_TRAFFIC_SOURCE = "profiles/r01_pmc_dominant_kernel.txt"
 
 
