@@ -66,8 +66,8 @@ def fill_state_dict(sd, base_seed):
 
 
 def rel_l2(a, b):
-    a = a.double().flatten()
-    b = b.double().flatten()
+    a = a.detach().double().flatten()
+    b = b.detach().double().flatten()
     d = (a - b).norm()
     n = b.norm()
     return float(d / n) if n > 0 else float(d)
@@ -75,7 +75,7 @@ def rel_l2(a, b):
 
 def max_rel(a, b):
     """max |a-b| / max |b| — the '1e-3 relative' figure used for conv activations."""
-    a = a.double()
-    b = b.double()
+    a = a.detach().double()
+    b = b.detach().double()
     den = float(b.abs().max())
     return float((a - b).abs().max()) / (den if den > 0 else 1.0)

@@ -56,15 +56,21 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [None, "128x128", "128x64", "64x128", "64x64"])
+# GEMM tile configurations forced through TDN_GEMM_CFG (ids of kCfgs in csrc/conv_igemm.hip): the production set —
+# 0: 64x64, 1: 64x128 (pipelined fragments), 3: 192x256 (8 waves), 25: 64x64 with two split-K wave groups,
+# 46: 128x128 (8 waves) — on top of whatever the library picks by itself (None)
+GEMM_CFGS = {None: 64, 0: 64, 1: 128, 3: 256, 25: 64, 46: 128}
+
+
+@pytest.mark.parametrize("tile", list(GEMM_CFGS))
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd(ops, case, tile):
     N, H, W, Cin, Cout, k, s = case
-    if tile and Cout % int(tile.split("x")[1]) != 0:
+    if tile is not None and Cout % GEMM_CFGS[tile] != 0:
         pytest.skip("tile does not divide Cout")
-    os.environ.pop("TDN_TILE", None)
-    if tile:
-        os.environ["TDN_TILE"] = tile
+    os.environ.pop("TDN_GEMM_CFG", None)
+    if tile is not None:
+        os.environ["TDN_GEMM_CFG"] = str(tile)
     try:
         x = det_tensor((N, Cin, H, W), 1, -1, 1)
         w = det_tensor((Cout, Cin, k, k), 2, -0.2, 0.2)
@@ -84,12 +90,17 @@ def test_conv_fwd(ops, case, tile):
         y0 = ops.conv2d_fwd(xg, wg, k, s, k // 2, out_f32=True)
         assert max_rel(nchw(y0), F.conv2d(x, w, None, s, k // 2)) <= TOL
     finally:
-        os.environ.pop("TDN_TILE", None)
+        os.environ.pop("TDN_GEMM_CFG", None)
 
 
+@pytest.mark.parametrize("tile", [None, 3, 25, 46])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_dgrad(ops, case):
+def test_conv_dgrad(ops, case, tile, monkeypatch):
     N, H, W, Cin, Cout, k, s = case
+    if tile is not None:
+        if Cin % GEMM_CFGS[tile] != 0:
+            pytest.skip("tile does not divide the dgrad GEMM's N = Cin")
+        monkeypatch.setenv("TDN_GEMM_CFG", str(tile))
     Ho, Wo = ops.conv_out_size(H, k, s, k // 2), ops.conv_out_size(W, k, s, k // 2)
     g = det_tensor((N, Cout, Ho, Wo), 11, -1, 1)
     w = det_tensor((Cout, Cin, k, k), 12, -0.2, 0.2)
@@ -322,3 +333,89 @@ def test_grouped_conv(ops, case):
     assert rel_l2(db.cpu(), beta.grad) <= TOL
     with pytest.raises(RuntimeError):
         ops.pack_gconv_weight(torch.zeros(96, 3, 3, 3, device="cuda"), 32)   # 96 channels: not a multiple of 64
+
+
+FULL_SIZE = [
+    # name, Cin, Cout, k, stride, H, W   — BASELINE shapes at the bench's 2 x 800 x 1344 batch
+    ("fpn_convs.0 3x3 256->256", 256, 256, 3, 1, 200, 336),     # the dominant launch: 192x256 tiles, M = 134400
+    ("layer1 conv3 1x1 64->256", 64, 256, 1, 1, 200, 336),
+    ("layer2.0 conv2 3x3 s2 128->128", 128, 128, 3, 2, 200, 336),
+    ("layer3 conv1 1x1 1024->256", 1024, 256, 1, 1, 50, 84),
+]
+
+
+@pytest.mark.parametrize("shape", FULL_SIZE, ids=[s[0] for s in FULL_SIZE])
+def test_full_size_layers(ops, shape, monkeypatch):
+    """BASELINE-size layers (the configurations only large M selects, e.g. the 192x256 tile at M = 134400), checked
+    through size-independent properties: (1) every tile configuration accumulates K in the same order, so the library's
+    own choice must equal the 64x64 tile BIT FOR BIT, forward and dgrad, with the fused epilogue; (2) a sample of
+    output pixels against an fp32 CPU convolution of the corresponding input patches; (3) linearity in the input by
+    a power of two (exact in bf16)."""
+    name, Cin, Cout, k, s, H, W = shape
+    N = 2
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, H, W, Cin, generator=g).bfloat16().cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) * 0.05).bfloat16().cuda()
+    scale = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    shift = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    Ho, Wo = ops.conv_out_size(H, k, s, k // 2), ops.conv_out_size(W, k, s, k // 2)
+    res = torch.randn(N, Ho, Wo, Cout, generator=g).bfloat16().cuda()
+
+    def fwd():
+        return ops.conv2d_fwd(x, w, k, s, k // 2, scale, shift, res, ops.ADD_SAME, True)
+
+    y_auto = fwd()
+    monkeypatch.setenv("TDN_GEMM_CFG", "0")
+    y_ref = fwd()
+    monkeypatch.delenv("TDN_GEMM_CFG")
+    assert torch.equal(y_auto, y_ref)
+    # (2) sampled pixels vs CPU fp32
+    xs, ws = x.float().cpu(), w.float().cpu().permute(0, 3, 1, 2).contiguous()
+    rng = torch.Generator().manual_seed(5)
+    pad = k // 2
+    for _ in range(24):
+        n = int(torch.randint(0, N, (1,), generator=rng))
+        oh = int(torch.randint(0, Ho, (1,), generator=rng))
+        ow = int(torch.randint(0, Wo, (1,), generator=rng))
+        patch = torch.zeros(1, Cin, k, k)
+        for kh in range(k):
+            for kw in range(k):
+                h, wq = oh * s - pad + kh, ow * s - pad + kw
+                if 0 <= h < H and 0 <= wq < W:
+                    patch[0, :, kh, kw] = xs[n, h, wq]
+        ref = F.conv2d(patch, ws).view(-1) * scale.cpu() + shift.cpu() + res[n, oh, ow].float().cpu()
+        ref = F.relu(ref)
+        got = y_auto[n, oh, ow].float().cpu()
+        assert bool(((got - ref).abs() <= ref.abs() * 2 ** -7 + 1e-5 * float(ref.abs().max() + 1)).all()), (n, oh, ow)
+    # (3) linearity: conv(4x) == 4 conv(x) exactly (no epilogue)
+    y1 = ops.conv2d_fwd(x, w, k, s, k // 2, out_f32=True)
+    y4 = ops.conv2d_fwd((x.float() * 4).bfloat16(), w, k, s, k // 2, out_f32=True)
+    assert torch.equal(y4, y1 * 4)
+    # dgrad: auto == 64x64 tile, with the fused (+ addend, ReLU mask) epilogue
+    gg = torch.randn(N, Ho, Wo, Cout, generator=g).bfloat16().cuda()
+    wd = (torch.randn(Cin, k, k, Cout, generator=g) * 0.05).bfloat16().cuda()
+    add = torch.randn(N, H, W, Cin, generator=g).bfloat16().cuda()
+    dx_auto = ops.conv2d_dgrad(gg, wd, (H, W), k, s, k // 2, add, ops.ADD_SAME, x)
+    monkeypatch.setenv("TDN_GEMM_CFG", "0")
+    dx_ref = ops.conv2d_dgrad(gg, wd, (H, W), k, s, k // 2, add, ops.ADD_SAME, x)
+    monkeypatch.delenv("TDN_GEMM_CFG")
+    assert torch.equal(dx_auto, dx_ref)
+    # wgrad at full size: the column sums (dbeta) are an exact-able checksum — sum of g over all pixels
+    dw, _, db = ops.conv2d_wgrad(x, gg, w, k, s, k // 2)
+    assert rel_l2(db.cpu(), gg.float().sum((0, 1, 2)).cpu()) <= 1e-4
+    # and the weight gradient against a CPU einsum on a channel sample (full K = all pixels)
+    co, ci = [0, Cout // 2, Cout - 1], [0, Cin - 1]
+    gs = gg.float().cpu()[..., co]                                    # N,Ho,Wo,3
+    for kh in range(k):
+        for kw in range(k):
+            xsub = torch.zeros(N, Ho, Wo, len(ci))
+            for a_, oh in enumerate(range(Ho)):
+                h = oh * s - pad + kh
+                if not 0 <= h < H:
+                    continue
+                ows = [ow for ow in range(Wo) if 0 <= ow * s - pad + kw < W]
+                wqs = [ow * s - pad + kw for ow in ows]
+                xsub[:, oh, ows] = xs[:, h, wqs][..., ci]
+            ref = torch.einsum("nhwo,nhwi->oi", gs, xsub)
+            got = dw[co][:, kh, kw][:, ci].cpu()
+            assert rel_l2(got, ref) <= 2e-3, (kh, kw)
