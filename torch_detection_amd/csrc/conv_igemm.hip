@@ -113,7 +113,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   static_assert(A_IT >= 1 && B_IT >= 1 && FM >= 1 && FN >= 1, "tile too small for this wave layout");
   static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "loader does not tile evenly");
   static_assert(NSTAGE >= 2 && LOADS * (NSTAGE - 2) < 64, "vmcnt immediate out of range");
-  static_assert(KG == 1 || (MODE == 0 || MODE == 6 || MODE == 9 || MODE == 10), "split-K groups: production schedules only");
+  static_assert(KG == 1 || (MODE == 0 || MODE == 6 || MODE == 9 || MODE == 10 || MODE == 11),
+                "split-K groups: production schedules only");
   static_assert(KG == 1 || BM * BN * 4 <= NSTAGE * STAGE, "partial sums must fit the group's LDS ring");
   constexpr bool EARLY_EPI = FN * FM <= 8;   // small tiles: fetch scale/shift before the K loop (registers to spare)
   // WIDE: the MFMA rows of channel-fragment i are weight rows  q*4FN + 4i + e  (q = row>>2, e = row&3) of the wave's
@@ -395,6 +396,32 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
         for (int kk = 0; kk < KSUB; ++kk) mfma_substep(sA, sB, kk);
       } else if constexpr (MODE == 4) {   // ABLATION (timing only, wrong results): loads only, no LDS reads / MFMA
         stage_load(fill);
+      } else if constexpr (MODE == 11) {
+        // MODE 6 with the two waves of every SIMD out of phase: waves with wm == 0 issue the next K-step's LDS-DMA
+        // before their MFMAs, the others between their two MFMA sub-steps — while one wave of a SIMD is held up
+        // issuing DMA pieces (~60-100 cycles each) its partner feeds the matrix pipe
+        static_assert(KSUB == 2 && WM == 2, "staggered DMA issue: BK = 64, two wave rows");
+        bf16x8_t wf[2][FN], xf[2][FM];
+#pragma unroll
+        for (int i = 0; i < FN; ++i) wf[0][i] = lds_read_b128(sB + i * W_STEP + rdw_off[0]);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) xf[0][j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[0]);
+        if (wm == 0) stage_load(fill);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) wf[1][i] = lds_read_b128(sB + i * W_STEP + rdw_off[1]);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) xf[1][j] = lds_read_b128(sA + j * 16 * ROWB + rd_off[1]);
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j) acc[i][j] = mfma16<F16>(wf[0][i], xf[0][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wm != 0) stage_load(fill);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j) acc[i][j] = mfma16<F16>(wf[1][i], xf[1][j], acc[i][j]);
       } else if constexpr (MODE == 9) {   // ABLATION: loads only, through registers instead of LDS-DMA
         stage_load_regs(fill);
       } else if constexpr (MODE == 10) {  // ABLATION: loads only, buffer_load ... lds
@@ -699,6 +726,9 @@ static const GemmCfg kCfgs[] = {
     {128, 128, 128, 2, 4, 2, 0, 0},  // 52
     {64, 64, 128, 2, 2, 2, 0, 2},    // 53 traced 50
     {64, 128, 128, 2, 4, 2, 0, 0},   // 54 8 waves
+    {192, 256, 64, 2, 4, 2, 11, 0},  // 55 staggered DMA issue (vs 3): K-step 2700 -> 2430 cycles traced, no gain in-step
+    {192, 256, 64, 2, 4, 2, 11, 2},  // 56 traced
+    {128, 128, 64, 2, 4, 2, 11, 0},  // 57 (vs 46)
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -848,6 +878,9 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
     case 52: return launch_gemm<128, 128, 128, 2, 4, 2, 0, 0>(p, maxM, stream);
     case 53: return launch_gemm<64, 64, 128, 2, 2, 2, 0, 2>(p, maxM, stream);
     case 54: return launch_gemm<64, 128, 128, 2, 4, 2, 0, 0>(p, maxM, stream);
+    case 55: return launch_gemm<192, 256, 64, 2, 4, 2, 11, 0>(p, maxM, stream);
+    case 56: return launch_gemm<192, 256, 64, 2, 4, 2, 11, 2>(p, maxM, stream);
+    case 57: return launch_gemm<128, 128, 64, 2, 4, 2, 11, 0>(p, maxM, stream);
     default: TDN_CHECK(false, "bad GEMM config id"); return -1;
   }
 }
