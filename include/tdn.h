@@ -92,7 +92,9 @@ int tdn_pack_stem_weight(const float* w, int Cout, void* w_fwd, int dtype, void*
 /* ---- convolution (nn.Conv2d.forward via resnet.py:42-59,97-119,253-258; fpn.py:92-108) ---- */
 
 /* y[N][Ho][Wo][Cout] = epilogue(conv(x[N][H][W][Cin], w_fwd)), square kernel k in {1,3},
- * stride in {1,2}, pad = k/2 (conv1x1_group / conv3x3_group / ConvModule of the hot path).
+ * stride in {1,2}; "same" padding: k = 1: pad 0; k = 3: pad = dilation in 1..32, exactly as conv3x3_group builds its
+ * convs (padding = dilation, models/utils/layers.py:20-32; ResNet(dilations=...), resnet.py:187-233) — the dilation of
+ * a 3x3 conv is read from `pad` in every tdn_*conv2d_* entry point.
  * Requires Cin % 64 == 0 and Cout % 64 == 0. */
 int tdn_conv2d_fwd(const void* x, const void* w_fwd, void* y, int N, int H, int W, int Cin,
                    int Cout, int k, int stride, int pad, const tdn_epilogue* ep, int dtype,

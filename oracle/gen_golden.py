@@ -385,6 +385,29 @@ def main():
                                                              if isinstance(x_, torch.nn.BatchNorm2d))}
     np.savez_compressed(os.path.join(GOLD, "resnext.npz"), **rx)
 
+    # ---- dilated stages: ResNet(strides=(1,2,1,1), dilations=(1,1,2,4)) ("DC5"-style), forward ------------------
+    dil = {}
+    for d_, seed in ((18, 2100), (50, 2101)):
+        m = RefResNet(d_, strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4))
+        sd = fill_state_dict(m.state_dict(), seed)
+        m.load_state_dict(sd)
+        m.train()
+        x = det_tensor((1, 3, 64, 96), seed + 10, -2.0, 2.0)
+        with torch.no_grad():
+            ref = m(x)
+            mine = O.resnet_forward(sd, x, d_, strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4))
+        for a_, b_ in zip(ref, mine):
+            assert torch.equal(a_, b_), "oracle != reference (dilated R%d forward)" % d_
+        if d_ == 18:
+            for i, t in enumerate(ref):
+                dil["r18/c%d" % (i + 2)] = t.numpy()
+        man["resnet%d_dilated" % d_] = {
+            "strides": [1, 2, 1, 1], "dilations": [1, 1, 2, 4], "state_seed": seed,
+            "input": {"shape": [1, 3, 64, 96], "seed": seed + 10, "lo": -2.0, "hi": 2.0},
+            "out_shapes": [list(t.shape) for t in ref],
+            "sum": [float(t.double().sum()) for t in ref], "abssum": [float(t.double().abs().sum()) for t in ref]}
+    np.savez_compressed(os.path.join(GOLD, "dilated.npz"), **dil)
+
     # ---- image batch staging: normalize -> flip -> pad to /32 -> CHW -> collate ------------
     from datasets.utils.image import img_flip, img_normalize, img_pad_size_divisor
     from datasets.utils import DataContainer

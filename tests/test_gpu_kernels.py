@@ -419,3 +419,29 @@ def test_full_size_layers(ops, shape, monkeypatch):
             ref = torch.einsum("nhwo,nhwi->oi", gs, xsub)
             got = dw[co][:, kh, kw][:, ci].cpu()
             assert rel_l2(got, ref) <= 2e-3, (kh, kw)
+
+
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, dilation, stride
+    (2, 14, 18, 64, 128, 2, 1),
+    (1, 13, 21, 128, 64, 4, 1),
+    (1, 16, 20, 64, 64, 2, 2),      # dilated and strided: 4 output-parity classes in the dgrad
+    (1, 9, 9, 256, 256, 8, 1),      # dilation larger than half the map: most taps fall outside
+])
+def test_dilated_conv(ops, case):
+    """3x3 convs with padding = dilation (conv3x3_group, layers.py:20-32; ResNet(dilations=...)): forward, dgrad,
+    wgrad against F.conv2d(dilation=)."""
+    N, H, W, Cin, Cout, d, s = case
+    x = det_tensor((N, Cin, H, W), 101, -1, 1).requires_grad_(True)
+    w = det_tensor((Cout, Cin, 3, 3), 102, -0.2, 0.2).requires_grad_(True)
+    ref = F.conv2d(x, w, None, s, d, d)
+    g = det_tensor(tuple(ref.shape), 103, -1, 1)
+    ref.backward(g)
+    y = ops.conv2d_fwd(nhwc(x.detach()), pack_w(w.detach()), 3, s, d, out_f32=True)
+    assert tuple(y.shape) == (N, ref.shape[2], ref.shape[3], Cout)
+    assert max_rel(nchw(y), ref.detach()) <= TOL
+    dx = ops.conv2d_dgrad(nhwc(g), pack_wd(w.detach()), (H, W), 3, s, d, out_f32=True)
+    assert max_rel(nchw(dx), x.grad) <= TOL
+    dw, _, db = ops.conv2d_wgrad(nhwc(x.detach()), nhwc(g), pack_w(w.detach()), 3, s, d)
+    assert rel_l2(dw.cpu().permute(0, 3, 1, 2), w.grad) <= TOL
+    assert rel_l2(db.cpu(), g.sum((0, 2, 3))) <= TOL

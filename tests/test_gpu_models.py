@@ -355,3 +355,30 @@ def test_graphed_step_matches_eager(T):
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(held["outs"], got_o))
     assert all(torch.equal(p.grad, g) for p, g in zip(params, got_g))
+
+
+def test_dilated_resnet_vs_golden(T, manifest, golden_dir):
+    """ResNet(strides=(1,2,1,1), dilations=(1,1,2,4)) forward against the reference golden (R18) and the oracle (R50),
+    plus a backward pass through the dilated stages."""
+    from oracle import torch_ref as O
+    gold = np.load(os.path.join(golden_dir, "dilated.npz"))
+    for d in (18, 50):
+        meta = manifest["resnet%d_dilated" % d]
+        m = T.ResNet(d, strides=tuple(meta["strides"]), dilations=tuple(meta["dilations"]))
+        sd = fill_state_dict(m.state_dict(), meta["state_seed"])
+        m.load_state_dict(sd)
+        m.cuda().train()
+        i = meta["input"]
+        x = det_tensor(tuple(i["shape"]), i["seed"], i["lo"], i["hi"])
+        outs = m(x.cuda())
+        assert [list(o.shape) for o in outs] == meta["out_shapes"]
+        if d == 18:
+            refs = [torch.from_numpy(gold["r18/c%d" % (k + 2)]) for k in range(4)]
+        else:
+            with torch.no_grad():
+                refs = O.resnet_forward(sd, x, d, strides=tuple(meta["strides"]), dilations=tuple(meta["dilations"]))
+        errs = [rel_l2(_f32(o), r) for o, r in zip(outs, refs)]
+        _record("resnet%d_dilated" % d, errs)
+        assert max(errs) <= 2e-2, errs
+        torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())

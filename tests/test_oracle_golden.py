@@ -292,3 +292,28 @@ def test_resnext_oracle_and_manifests_vs_reference_golden(manifest, golden_dir):
         ref = O.resnext_forward(sd, det_tensor(tuple(i["shape"]), i["seed"], i["lo"], i["hi"]), 50, 32)
     for k, t in enumerate(ref):
         assert np.array_equal(t.numpy(), gold["x50/c%d" % (k + 2)])
+
+
+def test_dilated_resnet_oracle_vs_reference_golden(manifest, golden_dir):
+    """ResNet(strides=(1,2,1,1), dilations=(1,1,2,4)): oracle forward == reference forward (R18 tensors stored, R50
+    checksums), and the drop-in module builds the same dilated convs (padding = dilation)."""
+    import torch_detection_amd as T
+    from oracle import torch_ref as O
+    torch.set_num_threads(4)
+    gold = np.load(os.path.join(golden_dir, "dilated.npz"))
+    for d in (18, 50):
+        meta = manifest["resnet%d_dilated" % d]
+        m = T.ResNet(d, strides=tuple(meta["strides"]), dilations=tuple(meta["dilations"]))
+        sd = fill_state_dict(m.state_dict(), meta["state_seed"])
+        i = meta["input"]
+        with torch.no_grad():
+            ref = O.resnet_forward(sd, det_tensor(tuple(i["shape"]), i["seed"], i["lo"], i["hi"]), d,
+                                   strides=tuple(meta["strides"]), dilations=tuple(meta["dilations"]))
+        assert [list(t.shape) for t in ref] == meta["out_shapes"]
+        if d == 18:
+            for k, t in enumerate(ref):
+                assert np.array_equal(t.numpy(), gold["r18/c%d" % (k + 2)])
+        else:
+            assert [float(t.double().sum()) for t in ref] == meta["sum"]
+    c = T.ResNet(50, strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4)).layer4[1].conv2
+    assert c.dilation == (4, 4) and c.padding == (4, 4)

@@ -11,8 +11,8 @@ Documented deviations:
   * ``frozen_stages >= 0`` implements the evident intent instead of raising AttributeError (resnet.py:288);
   * activations are bfloat16, outputs are bfloat16 NCHW-shaped tensors with channels_last strides;
   * the input image gets no gradient (nothing in the reference consumes one);
-  * ``use_gn=True``, ``bn_eval=False`` in training mode, and ``dilations != 1`` raise NotImplementedError
-    on ``forward`` (construction still works, so checkpoints and key lists stay inspectable).
+  * ``bn_eval=False`` in training mode (batch statistics) raises NotImplementedError on ``forward`` (construction
+    still works, so checkpoints and key lists stay inspectable); ``use_gn=True`` and ``dilations`` run on the HIP path.
 There is no CPU fallback: ``forward`` on a CPU tensor raises RuntimeError.
 """
 import logging
@@ -114,7 +114,7 @@ class ResNet(nn.Module):
         strides / dilations (Sequence[int]): per stage.
         out_indices (Sequence[int]): stages whose output is returned (a bare tensor if only one).
         frozen_stages (int): stem + stages [1..frozen_stages] get requires_grad=False in train mode.
-        use_gn (bool): GroupNorm instead of BatchNorm (constructible; not on the HIP path yet).
+        use_gn (bool): GroupNorm(32 groups) instead of BatchNorm.
         bn_eval (bool): keep BN layers in eval mode (running statistics) while training — reference default.
         bn_frozen (bool): also freeze BN weight / bias.
     """
@@ -184,8 +184,6 @@ class ResNet(nn.Module):
         ``dtype``: torch.bfloat16 / torch.float16 operands; default = ``self.compute_dtype`` (bfloat16)."""
         if dtype is None:
             dtype = getattr(self, 'compute_dtype', torch.bfloat16)
-        if any(d != 1 for d in self.dilations):
-            raise NotImplementedError('dilated ResNet stages are not on the HIP path yet')
         stem = HF.prepare_unit(self, 'stem', self.conv1, getattr(self, self.norm_name), True, dtype)
         blocks, out_blocks = [], []
         for i, layer_name in enumerate(self.res_layers):

@@ -916,26 +916,37 @@ static int check_conv_shape(int N, int H, int W, int Cin, int Cout, int k, int s
   TDN_CHECK(N > 0 && H > 0 && W > 0, "bad tensor shape N=%d H=%d W=%d", N, H, W);
   TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported (1 or 3)", k);
   TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported (1 or 2)", stride);
-  TDN_CHECK(pad == k / 2, "pad %d not supported for k=%d (need k/2)", pad, k);
+  // "same" convolutions only.  For k = 3 the padding IS the dilation, exactly as conv3x3_group builds them
+  // (padding = dilation, models/utils/layers.py:20-32): pad = d means taps at (-d, 0, +d)
+  TDN_CHECK((k == 1 && pad == 0) || (k == 3 && pad >= 1 && pad <= 32),
+            "pad %d not supported for k=%d (1x1: 0; 3x3: pad = dilation in 1..32)", pad, k);
   TDN_CHECK(Cin % 64 == 0 && Cout % 64 == 0, "channels must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
   TDN_CHECK((int64_t)N * H * W < (1ll << 31) / 4, "tensor too large for 32-bit pixel indexing");
   return 0;
 }
 
+// dilation of a "same" conv (see check_conv_shape) and its output size
+static inline int conv_dil(int k, int pad) { return k == 3 ? pad : 1; }
+static inline int conv_out_sz(int H, int k, int stride, int pad) {
+  return (H + 2 * pad - (conv_dil(k, pad) * (k - 1) + 1)) / stride + 1;
+}
+
 static void build_fwd(GemmParams& p, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
-  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int Ho = conv_out_sz(H, k, stride, pad), Wo = conv_out_sz(W, k, stride, pad);
+  const int d = conv_dil(k, pad);
   p.Hin = H; p.Win = W; p.Cpix = Cin; p.Ktap = Cin; p.wt_row = k * k * Cin;
   p.Hout = Ho; p.Wout = Wo; p.Cout = Cout; p.sa = stride; p.so = 1; p.ncls = 1; p.grouped = 0;
   GemmClass& c = p.cls[0];
   c.Ha = Ho; c.Wa = Wo; c.M = N * Ho * Wo; c.oh0 = 0; c.ow0 = 0; c.ntaps = 0;
   for (int kh = 0; kh < k; ++kh)
-    for (int kw = 0; kw < k; ++kw) c.taps[c.ntaps++] = pack_tap(kh - pad, kw - pad, kh * k + kw);
+    for (int kw = 0; kw < k; ++kw) c.taps[c.ntaps++] = pack_tap(kh * d - pad, kw * d - pad, kh * k + kw);
   class_divisors(c);
 }
 
 // Input gradient as a gather: dx[hi][wi] = sum over (kh,kw) with (hi+pad-kh) % s == 0 of g[(hi+pad-kh)/s] * w[kh][kw].
 static int build_dgrad(GemmParams& p, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
-  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int Ho = conv_out_sz(H, k, stride, pad), Wo = conv_out_sz(W, k, stride, pad);
+  const int d = conv_dil(k, pad);
   p.Hin = Ho; p.Win = Wo; p.Cpix = Cout; p.Ktap = Cout; p.wt_row = k * k * Cout;
   p.Hout = H; p.Wout = W; p.Cout = Cin; p.sa = 1; p.so = stride; p.grouped = 0;
   p.ncls = stride * stride;
@@ -950,10 +961,11 @@ static int build_dgrad(GemmParams& p, int N, int H, int W, int Cin, int Cout, in
       c.M = N * c.Ha * c.Wa;
       c.oh0 = ph; c.ow0 = pw; c.ntaps = 0;
       for (int kh = 0; kh < k; ++kh) {
-        if ((ph + pad - kh) % stride != 0) continue;
+        if ((ph + pad - kh * d) % stride != 0) continue;
         for (int kw = 0; kw < k; ++kw) {
-          if ((pw + pad - kw) % stride != 0) continue;
-          c.taps[c.ntaps++] = pack_tap((ph + pad - kh) / stride, (pw + pad - kw) / stride, kh * k + kw);
+          if ((pw + pad - kw * d) % stride != 0) continue;
+          // floor division (the numerator is negative for large dilations): it is an exact multiple of stride
+          c.taps[c.ntaps++] = pack_tap((ph + pad - kh * d) / stride, (pw + pad - kw * d) / stride, kh * k + kw);
         }
       }
       class_divisors(c);

@@ -434,7 +434,11 @@ static int run_wgrad(WgradParams& p, const WgradPlan& w, const void* w_fwd, cons
   return 0;
 }
 
-static int conv_out(int H, int k, int stride, int pad) { return (H + 2 * pad - k) / stride + 1; }
+// "same" convs: for k = 3 the padding is the dilation (conv3x3_group: padding = dilation, layers.py:20-32)
+static int conv_dil(int k, int pad) { return k == 3 ? pad : 1; }
+static int conv_out(int H, int k, int stride, int pad) {
+  return (H + 2 * pad - (conv_dil(k, pad) * (k - 1) + 1)) / stride + 1;
+}
 
 extern "C" int64_t tdn_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int k, int stride,
                                                int pad) {
@@ -461,7 +465,7 @@ extern "C" int tdn_conv2d_wgrad(const void* x, const void* g, const void* w_fwd,
   TDN_CHECK(x && g && w_fwd && dw && workspace, "tdn_conv2d_wgrad: NULL pointer");
   TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported", k);
   TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported", stride);
-  TDN_CHECK(pad == k / 2, "pad %d not supported for k=%d", pad, k);
+  TDN_CHECK((k == 1 && pad == 0) || (k == 3 && pad >= 1 && pad <= 32), "pad %d not supported for k=%d", pad, k);
   TDN_CHECK(Cin % 64 == 0 && Cout % 64 == 0, "channels must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
   const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
   const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, Cin, k * k);
@@ -470,7 +474,7 @@ extern "C" int tdn_conv2d_wgrad(const void* x, const void* g, const void* w_fwd,
   p.Hin = H; p.Win = W; p.Cpix = Cin; p.Ktap = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.sa = stride;
   p.ntaps = k * k;
   for (int kh = 0; kh < k; ++kh)
-    for (int kw = 0; kw < k; ++kw) p.taps[kh * k + kw] = (kh - pad + 64) | ((kw - pad + 64) << 8);
+    for (int kw = 0; kw < k; ++kw) p.taps[kh * k + kw] = (kh * conv_dil(k, pad) - pad + 64) | ((kw * conv_dil(k, pad) - pad + 64) << 8);
   return run_wgrad(p, w, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes, 0,
                    dtype, (hipStream_t)stream);
 }
@@ -491,7 +495,7 @@ extern "C" int tdn_gconv2d_wgrad(const void* x, const void* g, const void* w_fwd
   TDN_CHECK(x && g && w_fwd && dw && workspace, "tdn_gconv2d_wgrad: NULL pointer");
   TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported", k);
   TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported", stride);
-  TDN_CHECK(pad == k / 2, "pad %d not supported for k=%d", pad, k);
+  TDN_CHECK((k == 1 && pad == 0) || (k == 3 && pad >= 1 && pad <= 32), "pad %d not supported for k=%d", pad, k);
   TDN_CHECK(groups > 0 && C % groups == 0 && C % 64 == 0 && (C / groups) <= 64 && 64 % (C / groups) == 0,
             "grouped conv: need C %% 64 == 0 and channels per group dividing 64 (C=%d, groups=%d)", C, groups);
   const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
@@ -501,7 +505,7 @@ extern "C" int tdn_gconv2d_wgrad(const void* x, const void* g, const void* w_fwd
   p.Hin = H; p.Win = W; p.Cpix = C; p.Ktap = 64; p.Ho = Ho; p.Wo = Wo; p.Cout = C; p.sa = stride;
   p.ntaps = k * k;
   for (int kh = 0; kh < k; ++kh)
-    for (int kw = 0; kw < k; ++kw) p.taps[kh * k + kw] = (kh - pad + 64) | ((kw - pad + 64) << 8);
+    for (int kw = 0; kw < k; ++kw) p.taps[kh * k + kw] = (kh * conv_dil(k, pad) - pad + 64) | ((kw * conv_dil(k, pad) - pad + 64) << 8);
   return run_wgrad(p, w, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes,
                    4 * (C / groups), dtype, (hipStream_t)stream);
 }

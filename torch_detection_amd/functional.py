@@ -52,15 +52,17 @@ class ConvUnit(object):
                 raise NotImplementedError('grouped convolution %d -> %d with %d groups is not on the HIP path (needs '
                                           'equal channel counts, a multiple of 64, channels per group dividing 64)'
                                           % (conv.in_channels, conv.out_channels, conv.groups))
-        if conv.dilation != (1, 1):
-            raise NotImplementedError('dilated convolution is not on the HIP path yet')
+        # dilation: only as conv3x3_group builds it (padding = dilation, layers.py:20-32); the C ABI reads the dilation
+        # of a 3x3 conv from its padding
+        if conv.dilation != (1, 1) and not (kh == 3 and conv.dilation == conv.padding and conv.dilation[0] <= 32):
+            raise NotImplementedError('dilated convolution is only on the HIP path as a 3x3 with padding = dilation')
         if kh != kw or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
             raise NotImplementedError('only square kernels / strides / paddings are supported')
         if self.is_stem:
             if (self.Cin, self.stride, self.pad) != (3, 2, 3) or self.Cout % 64:
                 raise NotImplementedError('7x7 conv is only supported as the ResNet stem (3->64k, stride 2, pad 3)')
         else:
-            if kh not in (1, 3) or self.stride not in (1, 2) or self.pad != kh // 2:
+            if kh not in (1, 3) or self.stride not in (1, 2) or self.pad != (kh // 2) * conv.dilation[0]:
                 raise NotImplementedError('conv %dx%d stride %d pad %d is not on the HIP path' %
                                           (kh, kw, self.stride, self.pad))
             if self.Cin % 64 or self.Cout % 64:

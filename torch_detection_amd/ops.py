@@ -47,7 +47,10 @@ def _chk_vec(t, name, C):
 
 
 def conv_out_size(h, k, stride, pad):
-    return (h + 2 * pad - k) // stride + 1
+    """Output size of the "same" convs of the hot path: 1x1 with pad 0, 3x3 with pad = dilation (conv3x3_group builds
+    them with padding = dilation, layers.py:20-32), 3x3/s2 max pool."""
+    d = pad if k == 3 and pad > 1 else 1
+    return (h + 2 * pad - (d * (k - 1) + 1)) // stride + 1
 
 
 def make_epilogue(Cout, Ho, Wo, scale=None, shift=None, addend=None, addend_mode=ADD_NONE, relu=False,
