@@ -240,6 +240,20 @@ int tdn_gn_bwd(const void* g, const void* z, const float* stats, const float* ga
                int G, void* dz, float* dgamma, float* dbeta, float acc, void* workspace, int64_t workspace_bytes,
                int dtype, void* stream);
 
+/* ---- BatchNorm2d with batch statistics (training mode) ------------------------------------
+ * nn.BatchNorm2d as norm_layer builds it (models/utils/layers.py:50-54) when the backbone is NOT told to keep BN in eval
+ * mode — ResNet(bn_eval=False), models/backbone/resnet.py:270-276.  Same passes as GroupNorm with the statistics taken
+ * per channel over (N, H, W); running_mean / running_var (may both be NULL) are updated in place:
+ * r = (1 - momentum) r + momentum * batch value, unbiased variance.  stats (N,C,2) as in tdn_gn_fwd.
+ * Workspace: tdn_gn_workspace(N, H, W, C, C). */
+int tdn_bn_train_fwd(const void* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float momentum, int N, int H, int W, int C, float eps, const void* addend, int addend_mode,
+                     int relu, void* y, float* stats, void* workspace, int64_t workspace_bytes, int dtype,
+                     void* stream);
+int tdn_bn_train_bwd(const void* g, const void* z, const float* stats, const float* gamma, int N, int H, int W, int C,
+                     void* dz, float* dgamma, float* dbeta, float acc, void* workspace, int64_t workspace_bytes,
+                     int dtype, void* stream);
+
 /* ---- image batch staging -------------------------------------------
  * One launch for what the reference does per image on the host and then in collate():
  *   img_normalize            datasets/utils/image.py:87-105     (img - mean) / std, float32

@@ -408,6 +408,42 @@ def main():
             "sum": [float(t.double().sum()) for t in ref], "abssum": [float(t.double().abs().sum()) for t in ref]}
     np.savez_compressed(os.path.join(GOLD, "dilated.npz"), **dil)
 
+    # ---- BatchNorm with batch statistics: ResNet(18, bn_eval=False).train(), forward + backward ----------------
+    bt = {}
+    m = RefResNet(18, bn_eval=False)
+    sd = fill_state_dict(m.state_dict(), 2200)
+    m.load_state_dict(sd)
+    m.train()
+    assert all(x_.training for x_ in m.modules() if isinstance(x_, torch.nn.BatchNorm2d))
+    x = det_tensor((2, 3, 64, 96), 2210, -2.0, 2.0)
+    outs = m(x)
+    cots = [det_tensor(tuple(o.shape), 2220 + i, -1.0, 1.0) for i, o in enumerate(outs)]
+    torch.autograd.backward(outs, cots)
+    ps = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    with O.bn_training():
+        outs2 = O.resnet_forward(ps, x, 18)
+    torch.autograd.backward(outs2, cots)
+    for a_, b_ in zip(outs, outs2):
+        assert torch.equal(a_, b_), "oracle != reference (BN-train R18 forward)"
+    for k, p in m.named_parameters():
+        assert torch.equal(ps[k].grad, p.grad), "oracle != reference (BN-train grad %s)" % k
+    new_sd = m.state_dict()
+    for k in new_sd:
+        if "running" in k:
+            assert torch.equal(ps[k], new_sd[k]), "oracle != reference (running stat %s)" % k
+    for i, o in enumerate(outs):
+        bt["c%d" % (i + 2)] = o.detach().numpy()
+    keep = ["conv1.weight", "bn1.weight", "bn1.bias", "layer1.0.conv1.weight", "layer2.0.downsample.1.weight",
+            "layer2.1.conv1.weight", "layer3.1.bn2.bias", "layer4.1.bn2.weight"]
+    for k in keep:
+        bt["grad/" + k] = dict(m.named_parameters())[k].grad.numpy()
+    for k in ("bn1.running_mean", "bn1.running_var", "layer4.1.bn2.running_mean", "layer4.1.bn2.running_var"):
+        bt["stat/" + k] = new_sd[k].numpy()
+    np.savez_compressed(os.path.join(GOLD, "bn_train.npz"), **bt)
+    man["bn_train_r18"] = {"state_seed": 2200, "input": {"shape": [2, 3, 64, 96], "seed": 2210, "lo": -2.0, "hi": 2.0},
+                           "cot_seed0": 2220, "grad_keys": keep, "out_shapes": [list(o.shape) for o in outs],
+                           "num_batches_tracked_after": int(new_sd["bn1.num_batches_tracked"])}
+
     # ---- image batch staging: normalize -> flip -> pad to /32 -> CHW -> collate ------------
     from datasets.utils.image import img_flip, img_normalize, img_pad_size_divisor
     from datasets.utils import DataContainer

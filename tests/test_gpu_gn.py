@@ -80,3 +80,33 @@ def test_gn_bad_shapes(ops):
     w = torch.ones(64, device="cuda")
     with pytest.raises(RuntimeError):
         ops.gn_fwd(z, w, w, 48)       # groups do not divide channels
+
+
+@pytest.mark.parametrize("case", [(2, 64, 13, 21), (3, 256, 8, 12), (1, 1024, 5, 4)])
+def test_bn_train_fwd_bwd(ops, case):
+    """Training-mode BatchNorm2d (batch statistics, running-stat update) against F.batch_norm(training=True)."""
+    N, C, H, W = case
+    dt, ulp = torch.bfloat16, 2.0 ** -7
+    rq = lambda t: t.to(dt).float()   # noqa: E731
+    z = rq(det_tensor((N, C, H, W), 1, -2, 2, bf16=False) + 0.3).requires_grad_(True)
+    gamma = det_tensor((C,), 2, 0.5, 1.5, bf16=False).requires_grad_(True)
+    beta = det_tensor((C,), 3, -0.5, 0.5, bf16=False).requires_grad_(True)
+    rm0 = det_tensor((C,), 4, -0.2, 0.2, bf16=False)
+    rv0 = det_tensor((C,), 5, 0.5, 1.5, bf16=False)
+    res = rq(det_tensor((N, C, H, W), 6, -1, 1, bf16=False))
+    nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dt).cuda()   # noqa: E731
+    nc = lambda t: t.float().cpu().permute(0, 3, 1, 2).contiguous()            # noqa: E731
+    rm, rv = rm0.clone(), rv0.clone()
+    pre = F.batch_norm(z, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    ref = F.relu(pre + res)
+    rmg, rvg = rm0.clone().cuda(), rv0.clone().cuda()
+    y, stats = ops.bn_train_fwd(nh(z), gamma.detach().cuda(), beta.detach().cuda(), rmg, rvg, 0.1, 1e-5, nh(res), True)
+    err = (nc(y) - ref.detach()).abs()
+    assert bool((err <= ref.detach().abs() * ulp + 1e-5 * float(ref.detach().abs().max())).all())
+    assert torch.allclose(rmg.cpu(), rm, rtol=1e-5, atol=1e-6) and torch.allclose(rvg.cpu(), rv, rtol=1e-5, atol=1e-6)
+    cot = rq(det_tensor((N, C, H, W), 7, -1, 1, bf16=False))
+    g = rq(cot * (ref.detach() > 0).float())
+    pre.backward(g)
+    dz, dg, db = ops.bn_train_bwd(nh(g), nh(z), stats, gamma.detach().cuda())
+    assert rel_l2(dg.cpu(), gamma.grad) <= 1e-3 and rel_l2(db.cpu(), beta.grad) <= 1e-3
+    assert max_rel(nc(dz), z.grad) <= 2 * ulp

@@ -317,3 +317,30 @@ def test_dilated_resnet_oracle_vs_reference_golden(manifest, golden_dir):
             assert [float(t.double().sum()) for t in ref] == meta["sum"]
     c = T.ResNet(50, strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4)).layer4[1].conv2
     assert c.dilation == (4, 4) and c.padding == (4, 4)
+
+
+def test_bn_training_oracle_vs_reference_golden(manifest, golden_dir):
+    """ResNet(18, bn_eval=False).train(): BatchNorm with batch statistics.  The oracle (``with bn_training()``)
+    reproduces the reference's outputs, sampled gradients and updated running statistics bit for bit."""
+    from oracle import torch_ref as O
+    import torch_detection_amd as T
+    torch.set_num_threads(4)
+    meta = manifest["bn_train_r18"]
+    gold = np.load(os.path.join(golden_dir, "bn_train.npz"))
+    m = T.ResNet(18, bn_eval=False)
+    m.train()
+    assert all(x.training for x in m.modules() if isinstance(x, torch.nn.BatchNorm2d))   # resnet.py:270-276
+    sd = fill_state_dict(m.state_dict(), meta["state_seed"])
+    ps = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    i = meta["input"]
+    x = det_tensor(tuple(i["shape"]), i["seed"], i["lo"], i["hi"])
+    with O.bn_training():
+        outs = O.resnet_forward(ps, x, 18)
+    torch.autograd.backward(outs, [det_tensor(tuple(o.shape), meta["cot_seed0"] + j, -1, 1)
+                                   for j, o in enumerate(outs)])
+    for j, o in enumerate(outs):
+        assert np.array_equal(o.detach().numpy(), gold["c%d" % (j + 2)])
+    for k in meta["grad_keys"]:
+        assert np.array_equal(ps[k].grad.numpy(), gold["grad/" + k]), k
+    for k in ("bn1.running_mean", "bn1.running_var", "layer4.1.bn2.running_mean", "layer4.1.bn2.running_var"):
+        assert np.array_equal(ps[k].detach().numpy(), gold["stat/" + k]), k

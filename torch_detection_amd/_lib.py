@@ -84,6 +84,10 @@ SIGNATURES = {
                            c_i64, c_int, c_void_p]),
     "tdn_gn_bwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_i64,
                            c_int, c_void_p]),
+    "tdn_bn_train_fwd": (c_int, [c_void_p] * 5 + [c_float] + [c_int] * 4 + [c_float, c_void_p, c_int, c_int, c_void_p,
+                                 c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "tdn_bn_train_bwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_i64,
+                                 c_int, c_void_p]),
     "tdn_collate_images": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32),
                                    ctypes.POINTER(ctypes.c_uint8), c_int, c_int, ctypes.POINTER(c_float),
                                    ctypes.POINTER(c_float), c_int, c_int, c_void_p, c_int, c_int, c_void_p]),

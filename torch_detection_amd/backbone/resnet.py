@@ -11,8 +11,7 @@ Documented deviations:
   * ``frozen_stages >= 0`` implements the evident intent instead of raising AttributeError (resnet.py:288);
   * activations are bfloat16, outputs are bfloat16 NCHW-shaped tensors with channels_last strides;
   * the input image gets no gradient (nothing in the reference consumes one);
-  * ``bn_eval=False`` in training mode (batch statistics) raises NotImplementedError on ``forward`` (construction
-    still works, so checkpoints and key lists stay inspectable); ``use_gn=True`` and ``dilations`` run on the HIP path.
+  * ``use_gn=True``, ``dilations`` and ``bn_eval=False`` (BatchNorm with batch statistics) all run on the HIP path.
 There is no CPU fallback: ``forward`` on a CPU tensor raises RuntimeError.
 """
 import logging

@@ -225,6 +225,71 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* 
   }
 }
 
+// ---- training-mode BatchNorm2d (batch statistics): the same three passes with the statistics taken per channel over
+// the whole batch (N, H, W) instead of per (sample, group).  Only the two small middle kernels differ; stats / coef
+// are still written per (sample, channel) — identical for every sample — so the element-wise passes are shared. ----
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ part, GnGeom ge,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, float momentum,
+                                                            float* running_mean, float* running_var,
+                                                            float* __restrict__ stats, float* __restrict__ coef) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= ge.C) return;
+  double s = 0.0, ss = 0.0;
+  for (int n = 0; n < ge.N; ++n)
+    for (int k = 0; k < ge.chunks; ++k) {
+      const float* q = part + (((int64_t)n * ge.chunks + k) * 2) * ge.C + c;
+      s += (double)q[0];
+      ss += (double)q[ge.C];
+    }
+  const double cnt = (double)ge.N * ge.HW;
+  const double mu = s / cnt;
+  double var = ss / cnt - mu * mu;             // biased variance normalises (nn.BatchNorm2d, training)
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float muf = (float)mu;
+  const float a = rstd * gamma[c], b = beta[c] - muf * a;
+  for (int n = 0; n < ge.N; ++n) {
+    stats[((int64_t)n * ge.C + c) * 2] = muf;
+    stats[((int64_t)n * ge.C + c) * 2 + 1] = rstd;
+    coef[((int64_t)n * ge.C + c) * 2] = a;
+    coef[((int64_t)n * ge.C + c) * 2 + 1] = b;
+  }
+  if (running_mean && running_var) {           // running statistics: unbiased variance, momentum update
+    const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_coef_kernel(const float* __restrict__ part, GnGeom ge,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ stats,
+                                                               float* __restrict__ coef3, float* dgamma, float* dbeta,
+                                                               float acc) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= ge.C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = 0; n < ge.N; ++n)
+    for (int k = 0; k < ge.chunks; ++k) {
+      const float* q = part + (((int64_t)n * ge.chunks + k) * 2) * ge.C + c;
+      s1 += q[0];
+      s2 += q[ge.C];
+    }
+  const float gm = gamma[c];
+  const float cnt = (float)ge.N * (float)ge.HW;
+  const float m1 = gm * s1 / cnt, m2 = gm * s2 / cnt;
+  const float mu = stats[(int64_t)c * 2], r = stats[(int64_t)c * 2 + 1];
+  for (int n = 0; n < ge.N; ++n) {
+    float* o = coef3 + ((int64_t)n * ge.C + c) * 3;
+    o[0] = r * gm;
+    o[1] = -r * r * m2;
+    o[2] = -r * m1 + mu * r * r * m2;
+  }
+  dgamma[c] = (acc != 0.f) ? acc * dgamma[c] + s2 : s2;
+  dbeta[c] = (acc != 0.f) ? acc * dbeta[c] + s1 : s1;
+}
+
 int make_geom(GnGeom& ge, int N, int H, int W, int C, int G) {
   TDN_CHECK(N > 0 && H > 0 && W > 0, "GroupNorm: bad shape N=%d H=%d W=%d", N, H, W);
   TDN_CHECK(C >= 64 && C <= 2048 && (C & (C - 1)) == 0, "GroupNorm: C=%d must be a power of two in 64..2048", C);
@@ -305,6 +370,72 @@ extern "C" int tdn_gn_bwd(const void* g, const void* z, const float* stats, cons
   else
     hipLaunchKernelGGL((gn_partial_kernel<1, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
   hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(ceil_div(C, kThreads)), dim3(kThreads), 0, st, part, ge, gamma, stats,
+                     coef3, dgamma, dbeta, acc);
+  const int64_t total = (int64_t)N * ge.HW * ge.C8;
+  int grid = (int)((total + kThreads - 1) / kThreads);
+  if (grid > 8192) grid = 8192;
+  TDN_LAUNCH_T(gn_bwd_apply_kernel, dtype, dim3(grid), dim3(kThreads), st, (const bf16_t*)g, (const bf16_t*)z, coef3,
+               ge, (bf16_t*)dz);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Training-mode nn.BatchNorm2d (models/utils/layers.py:50-54 with ResNet(bn_eval=False), resnet.py:270-276): batch
+// statistics over (N, H, W), running statistics updated in place (momentum; unbiased variance) when given.
+// Workspace: tdn_gn_workspace(N, H, W, C, C).
+extern "C" int tdn_bn_train_fwd(const void* z, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float momentum, int N, int H, int W, int C, float eps,
+                                const void* addend, int addend_mode, int relu, void* y, float* stats, void* workspace,
+                                int64_t workspace_bytes, int dtype, void* stream) {
+  TDN_CHECK_DTYPE(dtype);
+  TDN_CHECK(z && gamma && beta && y && stats && workspace, "tdn_bn_train_fwd: NULL pointer");
+  TDN_CHECK((running_mean == nullptr) == (running_var == nullptr), "tdn_bn_train_fwd: give both running stats or none");
+  TDN_CHECK(!addend || addend_mode == TDN_ADD_SAME || addend_mode == TDN_ADD_UP2X,
+            "tdn_bn_train_fwd: addend_mode %d (TDN_ADD_SAME or TDN_ADD_UP2X)", addend_mode);
+  TDN_CHECK(!(addend && addend_mode == TDN_ADD_UP2X) || (H % 2 == 0 && W % 2 == 0),
+            "tdn_bn_train_fwd: UP2X addend needs even H, W (got %dx%d)", H, W);
+  const int up_w = (addend && addend_mode == TDN_ADD_UP2X) ? W / 2 : 0;
+  GnGeom ge;
+  if (make_geom(ge, N, H, W, C, C)) return -1;
+  TDN_CHECK(workspace_bytes >= ws_floats(ge) * 4 && ((uintptr_t)workspace & 15) == 0,
+            "tdn_bn_train_fwd: workspace too small or misaligned");
+  float* part = (float*)workspace;
+  float* coef = part + (int64_t)ge.N * ge.chunks * 2 * ge.C;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 gp(ge.chunks, N);
+  if (dtype == TDN_F16)
+    hipLaunchKernelGGL((gn_partial_kernel<0, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
+  else
+    hipLaunchKernelGGL((gn_partial_kernel<0, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(C, kThreads)), dim3(kThreads), 0, st, part, ge, gamma, beta, eps,
+                     momentum, running_mean, running_var, stats, coef);
+  const int64_t total = (int64_t)N * ge.HW * ge.C8;
+  int grid = (int)((total + kThreads - 1) / kThreads);
+  if (grid > 8192) grid = 8192;
+  TDN_LAUNCH_T(gn_apply_kernel, dtype, dim3(grid), dim3(kThreads), st, (const bf16_t*)z, coef, (const bf16_t*)addend,
+               relu, up_w, ge, (bf16_t*)y);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tdn_bn_train_bwd(const void* g, const void* z, const float* stats, const float* gamma, int N, int H,
+                                int W, int C, void* dz, float* dgamma, float* dbeta, float acc, void* workspace,
+                                int64_t workspace_bytes, int dtype, void* stream) {
+  TDN_CHECK_DTYPE(dtype);
+  TDN_CHECK(g && z && stats && gamma && dz && dgamma && dbeta && workspace, "tdn_bn_train_bwd: NULL pointer");
+  GnGeom ge;
+  if (make_geom(ge, N, H, W, C, C)) return -1;
+  TDN_CHECK(workspace_bytes >= ws_floats(ge) * 4 && ((uintptr_t)workspace & 15) == 0,
+            "tdn_bn_train_bwd: workspace too small or misaligned");
+  float* part = (float*)workspace;
+  float* coef3 = part + (int64_t)ge.N * ge.chunks * 2 * ge.C;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 gp(ge.chunks, N);
+  if (dtype == TDN_F16)
+    hipLaunchKernelGGL((gn_partial_kernel<1, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
+  else
+    hipLaunchKernelGGL((gn_partial_kernel<1, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(ceil_div(C, kThreads)), dim3(kThreads), 0, st, part, ge, gamma, stats,
                      coef3, dgamma, dbeta, acc);
   const int64_t total = (int64_t)N * ge.HW * ge.C8;
   int grid = (int)((total + kThreads - 1) / kThreads);

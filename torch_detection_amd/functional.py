@@ -75,6 +75,9 @@ class ConvUnit(object):
         # conv (raw) -> tdn_gn_fwd; ``bn`` keeps holding the norm module either way (its weight / bias are the
         # second and third parameter of the unit)
         self.gn = isinstance(bn, nn.GroupNorm)
+        # BatchNorm2d in training mode (batch statistics; ResNet(bn_eval=False), resnet.py:270-276) cannot be folded
+        # either: decided at refresh() time from ``bn.training`` and run like GroupNorm (conv raw -> tdn_bn_train_fwd)
+        self.bnt = False
         if bn is not None and conv.bias is not None:
             raise NotImplementedError('a conv with both a bias and a norm layer is not on the HIP path (the reference '
                                       'builds its normalised convs without bias: layers.py:12-47, fpn.py:26)')
@@ -98,8 +101,8 @@ class ConvUnit(object):
 
     def _version_key(self):
         w = self.conv.weight
-        key = [w.data_ptr(), w._version, w.device, self.dtype]
-        if self.bn is not None and not self.gn:
+        key = [w.data_ptr(), w._version, w.device, self.dtype, self.bn is not None and self.bn.training]
+        if self.bn is not None and not self.gn and not self.bn.training:
             for t in (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var):
                 key += [t.data_ptr(), t._version]
         elif self.conv.bias is not None:
@@ -108,11 +111,10 @@ class ConvUnit(object):
 
     def refresh(self):
         """(Re)pack weights / fold BN if any source tensor changed since the last call."""
-        if self.bn is not None and not self.gn and self.bn.training:
-            raise NotImplementedError(
-                'BatchNorm2d in training mode (batch statistics) is not on the HIP path; the reference default '
-                'ResNet(bn_eval=True) keeps BN in eval mode (resnet.py:270-276) — call .train()/.eval() on the '
-                'ResNet, or .eval() on this module')
+        self.bnt = self.bn is not None and not self.gn and self.bn.training
+        if self.bnt and (self.bn.momentum is None or not self.bn.affine):
+            raise NotImplementedError('training-mode BatchNorm2d needs affine=True and a numeric momentum on the HIP '
+                                      'path (cumulative averaging / affine=False are not implemented)')
         w = self.conv.weight
         if not w.is_cuda:
             raise RuntimeError('torch_detection_amd modules run on the MI355X HIP path only: move the module to '
@@ -123,7 +125,7 @@ class ConvUnit(object):
         with torch.no_grad():
             if w.dtype != torch.float32:
                 raise NotImplementedError('parameters must be float32 (bf16 operands are derived on the fly)')
-            if self.gn:
+            if self.gn or self.bnt:
                 self.scale = self.shift = self.invstd = self.mean = None   # gamma / beta are read at launch time
             elif self.bn is not None:
                 self.scale, self.shift, self.invstd = ops.bn_fold(self.bn.weight, self.bn.bias, self.bn.running_mean,
@@ -221,7 +223,7 @@ def _gn_store(u):
 
 def unit_fwd(u, x, addend=None, addend_mode=ADD_NONE, relu=None):
     relu = u.relu if relu is None else relu
-    if not u.gn:
+    if not (u.gn or u.bnt):
         if u.groups > 1:
             return ops.gconv2d_fwd(x, u.w_fwd, u.groups, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode,
                                    relu)
@@ -232,9 +234,22 @@ def unit_fwd(u, x, addend=None, addend_mode=ADD_NONE, relu=None):
         z = ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad)
     if addend is None:
         addend_mode = ADD_SAME
-    y, stats = ops.gn_fwd(z, u.bn.weight, u.bn.bias, u.bn.num_groups, u.bn.eps, addend, relu, addend_mode)
+    y, stats = _dyn_norm_fwd(u, z, addend, relu, addend_mode)
     _gn_store(u)[u] = (z, stats)
     return y
+
+
+def _dyn_norm_fwd(u, z, addend, relu, addend_mode=ADD_SAME):
+    """GroupNorm, or BatchNorm2d with batch statistics (running statistics and num_batches_tracked updated like
+    nn.BatchNorm2d.forward does), + addend + ReLU on a raw conv output."""
+    if u.gn:
+        return ops.gn_fwd(z, u.bn.weight, u.bn.bias, u.bn.num_groups, u.bn.eps, addend, relu, addend_mode)
+    bn = u.bn
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    out = ops.bn_train_fwd(z, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, addend, relu, addend_mode)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return out
 
 
 def _gn_dz(u, g):
@@ -248,7 +263,10 @@ def _gn_dz(u, g):
     dg = db = None
     if u.sink is not None:
         dg, db = u.sink[1], u.sink[2]
-    dz, dg, db = ops.gn_bwd(g, z, stats, u.bn.weight, u.bn.num_groups, dg, db)
+    if u.gn:
+        dz, dg, db = ops.gn_bwd(g, z, stats, u.bn.weight, u.bn.num_groups, dg, db)
+    else:
+        dz, dg, db = ops.bn_train_bwd(g, z, stats, u.bn.weight, dg, db)
     st[(u, 'dz')] = (g.data_ptr(), dz, dg, db)
     return dz
 
@@ -256,7 +274,7 @@ def _gn_dz(u, g):
 def unit_dgrad(u, g, in_hw, addend=None, addend_mode=ADD_NONE, mask_src=None):
     if addend is None:
         addend_mode = ADD_NONE
-    if u.gn:
+    if u.gn or u.bnt:
         g = _gn_dz(u, g)
     if u.groups > 1:
         return ops.gconv2d_dgrad(g, u.w_dgrad, u.groups, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
@@ -314,12 +332,13 @@ def unit_wgrad(u, x_in, g, img_hw=None):
     dev = g.device
     dg = db = None
     gn_affine = None
-    if u.gn:
-        g = _gn_dz(u, g)                       # dL/dz; the affine gradients come from the GroupNorm kernel
+    dyn = u.gn or u.bnt
+    if dyn:
+        g = _gn_dz(u, g)                       # dL/dz; the affine gradients come from the norm kernel
         gn_affine = _gn_store(u)[(u, 'dz')][2:]
     if sink is not None:
         dw, d0, d1 = sink
-        if u.gn:
+        if dyn:
             pass                                # dgamma / dbeta were written into the sink by _gn_dz
         elif u.bn is not None:
             dg, db = d0, d1
@@ -329,9 +348,9 @@ def unit_wgrad(u, x_in, g, img_hw=None):
         # outputs are allocated on the main stream (their consumers live there); only the kernels move
         dw = torch.empty((u.Cout, 3, 7, 7) if u.is_stem else (u.Cout, u.k, u.k, u.Cin // u.groups),
                          dtype=torch.float32, device=dev)
-        if u.bn is not None and not u.gn:
+        if u.bn is not None and not dyn:
             dg = torch.empty(u.Cout, dtype=torch.float32, device=dev)
-        if (u.bn is not None and not u.gn) or u.conv.bias is not None:
+        if (u.bn is not None and not dyn) or u.conv.bias is not None:
             db = torch.empty(u.Cout, dtype=torch.float32, device=dev)
     side = _side_stream(dev)
     prev = None
@@ -367,7 +386,7 @@ def unit_wgrad(u, x_in, g, img_hw=None):
         u.on_grads(u, side)
     if sink is not None:
         return [None] * len(u.params())
-    if u.gn:
+    if dyn:
         return [dw_view, gn_affine[0], gn_affine[1]]
     if u.bn is not None:
         return [dw_view, dg, db]
@@ -490,10 +509,10 @@ def _block_bwd(b, saved, g, extra, mask_src, need_dx):
 
 def _stem_fwd(u, xp, hw):
     """conv7x7/s2 + norm + ReLU of the stem (resnet.py:254-257): BN folded into the conv epilogue, or GroupNorm."""
-    if not u.gn:
+    if not (u.gn or u.bnt):
         return ops.stem_conv_fwd(xp, u.w_fwd, hw, u.scale, u.shift, True)
     z = ops.stem_conv_fwd(xp, u.w_fwd, hw, None, None, False)
-    s, stats = ops.gn_fwd(z, u.bn.weight, u.bn.bias, u.bn.num_groups, u.bn.eps, None, True)
+    s, stats = _dyn_norm_fwd(u, z, None, True)
     _gn_store(u)[u] = (z, stats)
     return s
 

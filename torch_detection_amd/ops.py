@@ -624,3 +624,54 @@ def gconv2d_wgrad(x, g, w_fwd, groups, k, stride, pad, scale=None, mean=None, in
                                      _ptr(ws), ws.numel(), dtype_code(x.dtype), _lib.stream_ptr()),
                "tdn_gconv2d_wgrad")
     return dw, dgamma, dbeta
+
+
+# ---- BatchNorm2d with batch statistics (training mode) ----------------------------------------------------
+def bn_train_fwd(z, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, addend=None,
+                 relu=False, addend_mode=ADD_SAME):
+    """y = relu?(BatchNorm_train(z) (+ addend)); running statistics (if given) are updated in place like
+    nn.BatchNorm2d does.  Returns (y, stats) with stats (N, C, 2) float32 for the backward."""
+    _chk_act(z, "z")
+    N, H, W, C = z.shape
+    _chk_vec(gamma.detach(), "gamma", C)
+    _chk_vec(beta.detach(), "beta", C)
+    _chk_vec(running_mean, "running_mean", C)
+    _chk_vec(running_var, "running_var", C)
+    if (running_mean is None) != (running_var is None):
+        raise ValueError("bn_train_fwd: give both running statistics or none")
+    if addend is not None:
+        _chk_act(addend, "addend", C, z.dtype)
+        exp = (N, H, W, C) if addend_mode == ADD_SAME else (N, H // 2, W // 2, C)
+        if addend_mode not in (ADD_SAME, ADD_UP2X) or tuple(addend.shape) != exp:
+            raise RuntimeError("epilogue addend of spatial size %s does not match output %s (mode %d)" %
+                               (tuple(addend.shape[1:3]), (H, W), addend_mode))
+    y = torch.empty_like(z)
+    stats = torch.empty(N, C, 2, dtype=torch.float32, device=z.device)
+    ws = _gn_ws(N, H, W, C, C, z.device)
+    _lib.check(_lib.load().tdn_bn_train_fwd(_ptr(z), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                            float(momentum), N, H, W, C, float(eps), _ptr(addend), int(addend_mode),
+                                            1 if relu else 0, _ptr(y), _ptr(stats), _ptr(ws), ws.numel(),
+                                            dtype_code(z.dtype), _lib.stream_ptr()), "tdn_bn_train_fwd")
+    return y, stats
+
+
+def bn_train_bwd(g, z, stats, gamma, dgamma=None, dbeta=None, accumulate=False):
+    """(dz, dgamma, dbeta) of training-mode BatchNorm from g = dL/dy (ReLU mask already applied)."""
+    _chk_act(z, "z")
+    _chk_act(g, "g", z.shape[3], z.dtype)
+    N, H, W, C = z.shape
+    if g.shape != z.shape or tuple(stats.shape) != (N, C, 2) or stats.dtype != torch.float32:
+        raise RuntimeError("bn_train_bwd: inconsistent shapes")
+    _chk_vec(gamma.detach(), "gamma", C)
+    if dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
+    if dbeta is None:
+        dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
+    _chk_vec(dgamma, "dgamma", C)
+    _chk_vec(dbeta, "dbeta", C)
+    dz = torch.empty_like(z)
+    ws = _gn_ws(N, H, W, C, C, z.device)
+    _lib.check(_lib.load().tdn_bn_train_bwd(_ptr(g), _ptr(z), _ptr(stats), _ptr(gamma), N, H, W, C, _ptr(dz),
+                                            _ptr(dgamma), _ptr(dbeta), 1.0 if accumulate else 0.0, _ptr(ws),
+                                            ws.numel(), dtype_code(z.dtype), _lib.stream_ptr()), "tdn_bn_train_bwd")
+    return dz, dgamma, dbeta
