@@ -230,6 +230,36 @@ def main():
         for k, p in pa.named_parameters():
             if k.startswith("pa_convs") or tag == "none":
                 pf["%s/grad/%s" % (tag, k)] = p.grad.numpy()
+    # RetinaNet-style extra levels: stride-2 convs on the last backbone input (pafpn.py:139-147), 6 outputs
+    pa = RefPAFPN(chans, 64, 6, add_extra_convs=True)
+    sdp = fill_state_dict(pa.state_dict(), 830)
+    pa.load_state_dict(sdp)
+    pins = [det_tensor((2, c, h, w), 840 + i, -1.0, 1.0).requires_grad_(True) for i, (c, (h, w)) in
+            enumerate(zip(chans, sizes))]
+    pouts = pa(pins)
+    pcots = [det_tensor(tuple(o.shape), 850 + i, -1.0, 1.0) for i, o in enumerate(pouts)]
+    torch.autograd.backward(pouts, pcots)
+    pps = {k: v.detach().clone().requires_grad_(True) for k, v in sdp.items()}
+    pins2 = [t.detach().clone().requires_grad_(True) for t in pins]
+    pouts2 = O.pafpn_forward(pps, pins2, 6, None, True)
+    torch.autograd.backward(pouts2, pcots)
+    for a, b in zip(pouts, pouts2):
+        assert torch.equal(a, b), "oracle != reference (PAFPN extra convs forward)"
+    for a, b in zip(pins, pins2):
+        assert torch.equal(a.grad, b.grad), "oracle != reference (PAFPN extra convs input grad)"
+    for k, p in pa.named_parameters():
+        assert torch.equal(pps[k].grad, p.grad), "oracle != reference (PAFPN extra convs grad %s)" % k
+    for i, o in enumerate(pouts):
+        pf["extra/out%d" % i] = o.detach().numpy()
+    for i, t in enumerate(pins):
+        pf["extra/din%d" % i] = t.grad.numpy()
+    for k in ("fpn_convs.5.conv.weight", "fpn_convs.5.conv.bias", "fpn_convs.4.conv.bias", "pa_convs2.2.conv.weight"):
+        pf["extra/grad/" + k] = dict(pa.named_parameters())[k].grad.numpy()
+    man["pafpn_extra"] = {"in_channels": chans, "out_channels": 64, "num_outs": 6,
+                          "sizes": [list(s_) for s_ in sizes], "N": 2, "state_seed": 830, "in_seed0": 840,
+                          "cot_seed0": 850, "state_keys": manifest_of(pa),
+                          "grad_keys": ["fpn_convs.5.conv.weight", "fpn_convs.5.conv.bias", "fpn_convs.4.conv.bias",
+                                        "pa_convs2.2.conv.weight"]}
     np.savez_compressed(os.path.join(GOLD, "pafpn.npz"), **pf)
     man["pafpn_small"] = {"in_channels": chans, "out_channels": 64, "num_outs": 5, "sizes": [list(s) for s in sizes],
                           "N": 2, "state_seed": 800, "in_seed0": 810, "cot_seed0": 820}

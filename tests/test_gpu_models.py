@@ -421,3 +421,30 @@ def test_bn_training_mode_vs_golden(T, manifest, golden_dir):
     with torch.no_grad():
         o_eval = m(det_tensor(tuple(i["shape"]), i["seed"], i["lo"], i["hi"]).cuda())
     assert all(bool(torch.isfinite(o).all()) for o in o_eval)
+
+
+def test_pafpn_extra_convs_vs_golden(T, manifest, golden_dir):
+    """PAFPN(add_extra_convs=True, num_outs=6): stride-2 conv levels on the last backbone input (pafpn.py:139-147),
+    including the reference's in-place ReLU on P6 (the returned P6 is rectified), against the reference golden."""
+    meta = manifest["pafpn_extra"]
+    gold = np.load(os.path.join(golden_dir, "pafpn.npz"))
+    pa = T.PAFPN(meta["in_channels"], meta["out_channels"], meta["num_outs"], add_extra_convs=True)
+    keys = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in pa.state_dict().items()]
+    assert keys == meta["state_keys"]
+    pa.load_state_dict(fill_state_dict(pa.state_dict(), meta["state_seed"]))
+    pa.cuda()
+    ins = [det_tensor((meta["N"], c, h, w), meta["in_seed0"] + i, -1, 1).cuda().requires_grad_(True)
+           for i, (c, (h, w)) in enumerate(zip(meta["in_channels"], meta["sizes"]))]
+    outs = pa(ins)
+    assert len(outs) == 6
+    torch.autograd.backward(outs, [det_tensor(tuple(o.shape), meta["cot_seed0"] + i, -1, 1).cuda().to(o.dtype)
+                                   for i, o in enumerate(outs)])
+    eo = [rel_l2(_f32(o), torch.from_numpy(gold["extra/out%d" % i])) for i, o in enumerate(outs)]
+    ei = [rel_l2(_f32(t.grad), torch.from_numpy(gold["extra/din%d" % i])) for i, t in enumerate(ins)]
+    ps = dict(pa.named_parameters())
+    eg = {k: rel_l2(_f32(ps[k].grad), torch.from_numpy(gold["extra/grad/" + k])) for k in meta["grad_keys"]}
+    _record("pafpn_extra", {"out": eo, "din": ei, "grad": eg})
+    assert max(eo) <= 1e-2, eo
+    assert max(ei) <= 3e-2, ei
+    assert max(eg.values()) <= 3e-2, eg
+    assert float(outs[4].min()) >= 0.0     # P6 comes back rectified (in-place ReLU of the reference)

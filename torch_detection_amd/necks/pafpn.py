@@ -66,15 +66,17 @@ class PAFPN(nn.Module):
 
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        if self.add_extra_convs and self.num_outs > len(self.lateral_convs):
-            raise NotImplementedError('PAFPN(add_extra_convs=True) extra stride-2 conv levels are not on the HIP '
-                                      'path yet')
         nlat = len(self.lateral_convs)
         dtype = HF.pick_dtype(self, inputs)
         lat = [m.hip_unit(dtype) for m in self.lateral_convs]
-        fpn = [m.hip_unit(dtype) for m in self.fpn_convs[:nlat]]
-        fnet = HF.FPNNet(lat, fpn, self.start_level, self.backbone_end_level, nlat, False, self.num_ins)
+        extra_convs = self.add_extra_convs and self.num_outs > nlat
+        # the extra stride-2 conv levels (pafpn.py:139-147) hang off the last backbone input exactly as in FPN
+        # (fpn.py:118-124): the FPN node computes them, the PA path then rebuilds the first nlat levels
+        fpn = [m.hip_unit(dtype) for m in (self.fpn_convs if extra_convs else self.fpn_convs[:nlat])]
+        fnet = HF.FPNNet(lat, fpn, self.start_level, self.backbone_end_level, self.num_outs if extra_convs else nlat,
+                         extra_convs, self.num_ins)
         P = HF.FPNFunction.apply(fnet, *(tuple(inputs) + tuple(fnet.params())))
         pnet = HF.PAPathNet([m.hip_unit(dtype) for m in self.pa_convs1], [m.hip_unit(dtype) for m in self.pa_convs2],
-                            self.num_outs - nlat)
-        return HF.PAPathFunction.apply(pnet, *(tuple(P) + tuple(pnet.params())))
+                            0 if extra_convs else self.num_outs - nlat)
+        outs = HF.PAPathFunction.apply(pnet, *(tuple(P[:nlat]) + tuple(pnet.params())))
+        return tuple(outs) + tuple(P[nlat:]) if extra_convs else outs
