@@ -448,3 +448,28 @@ def test_pafpn_extra_convs_vs_golden(T, manifest, golden_dir):
     assert max(ei) <= 3e-2, ei
     assert max(eg.values()) <= 3e-2, eg
     assert float(outs[4].min()) >= 0.0     # P6 comes back rectified (in-place ReLU of the reference)
+
+
+def test_fpn_extra_convs_vs_oracle(T):
+    """FPN(add_extra_convs=True, num_outs=6) (RetinaNet levels, fpn.py:118-124) against oracle/torch_ref.py, whose
+    extra-level code is pinned to the reference through the PAFPN golden (same lines, same in-place ReLU)."""
+    from oracle import torch_ref as O
+    chans, sizes = [64, 128, 256, 512], [(16, 24), (8, 12), (4, 6), (2, 3)]
+    fpn = T.FPN(chans, 64, 6, add_extra_convs=True)
+    sd = fill_state_dict(fpn.state_dict(), 860)
+    fpn.load_state_dict(sd)
+    fpn.cuda()
+    ins = [det_tensor((2, c, h, w), 870 + i, -1, 1) for i, (c, (h, w)) in enumerate(zip(chans, sizes))]
+    gins = [t.cuda().requires_grad_(True) for t in ins]
+    outs = fpn(gins)
+    cots = [det_tensor(tuple(o.shape), 880 + i, -1, 1) for i, o in enumerate(outs)]
+    torch.autograd.backward(outs, [c.cuda().to(o.dtype) for c, o in zip(cots, outs)])
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rins = [t.clone().requires_grad_(True) for t in ins]
+    routs = O.fpn_forward(ps, rins, 6, add_extra_convs=True)
+    torch.autograd.backward(routs, cots)
+    eo = [rel_l2(_f32(o), r.detach()) for o, r in zip(outs, routs)]
+    ei = [rel_l2(_f32(t.grad), r.grad) for t, r in zip(gins, rins)]
+    eg = {k: rel_l2(_f32(p.grad), ps[k].grad) for k, p in fpn.named_parameters()}
+    _record("fpn_extra", {"out": eo, "din": ei, "grad_max": max(eg.values())})
+    assert max(eo) <= 1e-2 and max(ei) <= 3e-2 and max(eg.values()) <= 3e-2, (eo, ei, eg)
