@@ -86,32 +86,53 @@ __global__ __launch_bounds__(kThreads) void gn_partial_kernel(const bf16_t* __re
   }
 }
 
-// [2]: one block per sample; thread per channel (strided): chunk sums -> group mean / rstd (double), then per-channel
-// stats[n][c] = (mu, rstd) and coef[n][c] = (a, b) with y = z*a + b.
-__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const float* __restrict__ part, GnGeom ge,
+// Sum of the per-chunk partials of channel c of sample n, both planes, by the KL chunk-lanes of a block (thread
+// (cl, kl) takes chunks kl, kl+KL, ...; lanes combined through LDS in lane order -> deterministic).  CB channels per
+// block, CB * KL = kThreads.  Returns the totals to every thread with kl == 0.
+__device__ __forceinline__ void chunk_totals(const float* __restrict__ part, const GnGeom& ge, int n, int c, int cl,
+                                             int kl, int CB, int KL, bool live, double* red /*[2][kThreads]*/,
+                                             double& s, double& ss) {
+  double a = 0.0, b = 0.0;
+  if (live) {
+    for (int k = kl; k < ge.chunks; k += KL) {
+      const float* q = part + (((int64_t)n * ge.chunks + k) * 2) * ge.C + c;
+      a += (double)q[0];
+      b += (double)q[ge.C];
+    }
+  }
+  red[kl * CB + cl] = a;
+  red[kThreads + kl * CB + cl] = b;
+  __syncthreads();
+  s = 0.0; ss = 0.0;
+  if (kl == 0) {
+    for (int j = 0; j < KL; ++j) { s += red[j * CB + cl]; ss += red[kThreads + j * CB + cl]; }
+  }
+  __syncthreads();
+}
+
+// [2]: block (sample n, channel block of CB = max(32, cpg) channels — whole groups); chunk sums -> group mean / rstd
+// (double), then per-channel stats[n][c] = (mu, rstd) and coef[n][c] = (a, b) with y = z*a + b.
+__global__ __launch_bounds__(kThreads) void gn_stats_kernel(const float* __restrict__ part, GnGeom ge, int CB,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
                                                             float* __restrict__ stats, float* __restrict__ coef) {
-  extern __shared__ double sh[];   // [2][C]
-  const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < ge.C; c += blockDim.x) {
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < ge.chunks; ++k) {
-      const float* q = part + (((int64_t)n * ge.chunks + k) * 2) * ge.C + c;
-      s += (double)q[0];
-      ss += (double)q[ge.C];
-    }
-    sh[c] = s;
-    sh[ge.C + c] = ss;
-  }
+  __shared__ double red[2 * kThreads];
+  __shared__ double tot[2 * kThreads];
+  const int n = blockIdx.y;
+  const int KL = kThreads / CB;
+  const int cl = threadIdx.x % CB, kl = threadIdx.x / CB;
+  const int c = blockIdx.x * CB + cl;
+  double s, ss;
+  chunk_totals(part, ge, n, c, cl, kl, CB, KL, c < ge.C, red, s, ss);
+  if (kl == 0) { tot[cl] = s; tot[kThreads + cl] = ss; }
   __syncthreads();
-  const double cnt = (double)ge.HW * ge.cpg;
-  for (int c = threadIdx.x; c < ge.C; c += blockDim.x) {
-    const int g0 = (c / ge.cpg) * ge.cpg;
-    double s = 0.0, ss = 0.0;
-    for (int j = 0; j < ge.cpg; ++j) { s += sh[g0 + j]; ss += sh[ge.C + g0 + j]; }
-    const double mu = s / cnt;
-    double var = ss / cnt - mu * mu;       // biased variance, like nn.GroupNorm
+  if (kl == 0 && c < ge.C) {
+    const int g0 = (cl / ge.cpg) * ge.cpg;
+    double gs = 0.0, gss = 0.0;
+    for (int j = 0; j < ge.cpg; ++j) { gs += tot[g0 + j]; gss += tot[kThreads + g0 + j]; }
+    const double cnt = (double)ge.HW * ge.cpg;
+    const double mu = gs / cnt;
+    double var = gss / cnt - mu * mu;       // biased variance, like nn.GroupNorm
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float muf = (float)mu;
@@ -157,36 +178,36 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ z, const float* __res
   }
 }
 
-// [2']: blocks of 256 consecutive channels (whole groups: cpg divides 256); per sample: chunk sums -> (s1, s2),
-// group means m1 = sum_c gamma*s1 / cnt, m2 = sum_c gamma*s2 / cnt, coefficients of dz = g*A + z*B + Cc;
+// [2']: block = channel block of CB = max(32, cpg) channels (whole groups), all samples in turn: chunk sums ->
+// (s1, s2), group means m1 = sum_c gamma*s1 / cnt, m2 = sum_c gamma*s2 / cnt, coefficients of dz = g*A + z*B + Cc;
 // across samples: dgamma = sum_n s2, dbeta = sum_n s1.
-__global__ __launch_bounds__(kThreads) void gn_bwd_coef_kernel(const float* __restrict__ part, GnGeom ge,
+__global__ __launch_bounds__(kThreads) void gn_bwd_coef_kernel(const float* __restrict__ part, GnGeom ge, int CB,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ stats,
                                                                float* __restrict__ coef3, float* dgamma, float* dbeta,
                                                                float acc) {
+  __shared__ double red[2 * kThreads];
   __shared__ float t1[kThreads], t2[kThreads];
-  const int c = blockIdx.x * kThreads + threadIdx.x;
+  const int KL = kThreads / CB;
+  const int cl = threadIdx.x % CB, kl = threadIdx.x / CB;
+  const int c = blockIdx.x * CB + cl;
   const bool live = c < ge.C;
   const float gm = live ? gamma[c] : 0.f;
   float dg = 0.f, db = 0.f;
   const float cnt = (float)ge.HW * (float)ge.cpg;
   for (int n = 0; n < ge.N; ++n) {
-    float s1 = 0.f, s2 = 0.f;
-    if (live) {
-      for (int k = 0; k < ge.chunks; ++k) {
-        const float* q = part + (((int64_t)n * ge.chunks + k) * 2) * ge.C + c;
-        s1 += q[0];
-        s2 += q[ge.C];
-      }
+    double d1, d2;
+    chunk_totals(part, ge, n, c, cl, kl, CB, KL, live, red, d1, d2);
+    const float s1 = (float)d1, s2 = (float)d2;
+    if (kl == 0) {
+      dg += s2;
+      db += s1;
+      t1[cl] = gm * s1;
+      t2[cl] = gm * s2;
     }
-    dg += s2;
-    db += s1;
-    t1[threadIdx.x] = gm * s1;
-    t2[threadIdx.x] = gm * s2;
     __syncthreads();
-    if (live) {
-      const int l0 = (threadIdx.x / ge.cpg) * ge.cpg;
+    if (kl == 0 && live) {
+      const int l0 = (cl / ge.cpg) * ge.cpg;
       float m1 = 0.f, m2 = 0.f;
       for (int j = 0; j < ge.cpg; ++j) { m1 += t1[l0 + j]; m2 += t2[l0 + j]; }
       m1 /= cnt;
@@ -199,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_coef_kernel(const float* __re
     }
     __syncthreads();
   }
-  if (live) {
+  if (kl == 0 && live) {
     dgamma[c] = (acc != 0.f) ? acc * dgamma[c] + dg : dg;
     dbeta[c] = (acc != 0.f) ? acc * dbeta[c] + db : db;
   }
@@ -228,20 +249,38 @@ __global__ void gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* 
 // ---- training-mode BatchNorm2d (batch statistics): the same three passes with the statistics taken per channel over
 // the whole batch (N, H, W) instead of per (sample, group).  Only the two small middle kernels differ; stats / coef
 // are still written per (sample, channel) — identical for every sample — so the element-wise passes are shared. ----
+// totals over ALL samples and chunks of channel c, by the KL lanes of a block of CB = 32 channels
+__device__ __forceinline__ void batch_totals(const float* __restrict__ part, const GnGeom& ge, int c, int cl, int kl,
+                                             int CB, int KL, bool live, double* red, double& s, double& ss) {
+  double a = 0.0, b = 0.0;
+  if (live) {
+    for (int k = kl; k < ge.N * ge.chunks; k += KL) {   // [n][chunk] is one flat index of the partials
+      const float* q = part + ((int64_t)k * 2) * ge.C + c;
+      a += (double)q[0];
+      b += (double)q[ge.C];
+    }
+  }
+  red[kl * CB + cl] = a;
+  red[kThreads + kl * CB + cl] = b;
+  __syncthreads();
+  s = 0.0; ss = 0.0;
+  if (kl == 0) {
+    for (int j = 0; j < KL; ++j) { s += red[j * CB + cl]; ss += red[kThreads + j * CB + cl]; }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ part, GnGeom ge,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, float momentum,
                                                             float* running_mean, float* running_var,
                                                             float* __restrict__ stats, float* __restrict__ coef) {
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  if (c >= ge.C) return;
-  double s = 0.0, ss = 0.0;
-  for (int n = 0; n < ge.N; ++n)
-    for (int k = 0; k < ge.chunks; ++k) {
-      const float* q = part + (((int64_t)n * ge.chunks + k) * 2) * ge.C + c;
-      s += (double)q[0];
-      ss += (double)q[ge.C];
-    }
+  __shared__ double red[2 * kThreads];
+  constexpr int CB = 32, KL = kThreads / CB;
+  const int cl = threadIdx.x % CB, kl = threadIdx.x / CB;
+  const int c = blockIdx.x * CB + cl;
+  double s, ss;
+  batch_totals(part, ge, c, cl, kl, CB, KL, c < ge.C, red, s, ss);
+  if (kl != 0 || c >= ge.C) return;
   const double cnt = (double)ge.N * ge.HW;
   const double mu = s / cnt;
   double var = ss / cnt - mu * mu;             // biased variance normalises (nn.BatchNorm2d, training)
@@ -267,15 +306,14 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_coef_kernel(const float* __re
                                                                const float* __restrict__ stats,
                                                                float* __restrict__ coef3, float* dgamma, float* dbeta,
                                                                float acc) {
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  if (c >= ge.C) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int n = 0; n < ge.N; ++n)
-    for (int k = 0; k < ge.chunks; ++k) {
-      const float* q = part + (((int64_t)n * ge.chunks + k) * 2) * ge.C + c;
-      s1 += q[0];
-      s2 += q[ge.C];
-    }
+  __shared__ double red[2 * kThreads];
+  constexpr int CB = 32, KL = kThreads / CB;
+  const int cl = threadIdx.x % CB, kl = threadIdx.x / CB;
+  const int c = blockIdx.x * CB + cl;
+  double d1, d2;
+  batch_totals(part, ge, c, cl, kl, CB, KL, c < ge.C, red, d1, d2);
+  if (kl != 0 || c >= ge.C) return;
+  const float s1 = (float)d1, s2 = (float)d2;
   const float gm = gamma[c];
   const float cnt = (float)ge.N * (float)ge.HW;
   const float m1 = gm * s1 / cnt, m2 = gm * s2 / cnt;
@@ -341,7 +379,8 @@ extern "C" int tdn_gn_fwd(const void* z, const float* gamma, const float* beta, 
     hipLaunchKernelGGL((gn_partial_kernel<0, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
   else
     hipLaunchKernelGGL((gn_partial_kernel<0, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(N), dim3(kThreads), 2 * C * sizeof(double), st, part, ge, gamma, beta, eps,
+  const int CB = ge.cpg > 32 ? ge.cpg : 32;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(ceil_div(C, CB), N), dim3(kThreads), 0, st, part, ge, CB, gamma, beta, eps,
                      stats, coef);
   const int64_t total = (int64_t)N * ge.HW * ge.C8;
   int grid = (int)((total + kThreads - 1) / kThreads);
@@ -369,7 +408,8 @@ extern "C" int tdn_gn_bwd(const void* g, const void* z, const float* stats, cons
     hipLaunchKernelGGL((gn_partial_kernel<1, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
   else
     hipLaunchKernelGGL((gn_partial_kernel<1, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
-  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(ceil_div(C, kThreads)), dim3(kThreads), 0, st, part, ge, gamma, stats,
+  const int CB = ge.cpg > 32 ? ge.cpg : 32;
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(ceil_div(C, CB)), dim3(kThreads), 0, st, part, ge, CB, gamma, stats,
                      coef3, dgamma, dbeta, acc);
   const int64_t total = (int64_t)N * ge.HW * ge.C8;
   int grid = (int)((total + kThreads - 1) / kThreads);
@@ -407,7 +447,7 @@ extern "C" int tdn_bn_train_fwd(const void* z, const float* gamma, const float* 
     hipLaunchKernelGGL((gn_partial_kernel<0, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
   else
     hipLaunchKernelGGL((gn_partial_kernel<0, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(C, kThreads)), dim3(kThreads), 0, st, part, ge, gamma, beta, eps,
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(C, 32)), dim3(kThreads), 0, st, part, ge, gamma, beta, eps,
                      momentum, running_mean, running_var, stats, coef);
   const int64_t total = (int64_t)N * ge.HW * ge.C8;
   int grid = (int)((total + kThreads - 1) / kThreads);
@@ -435,7 +475,7 @@ extern "C" int tdn_bn_train_bwd(const void* g, const void* z, const float* stats
     hipLaunchKernelGGL((gn_partial_kernel<1, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
   else
     hipLaunchKernelGGL((gn_partial_kernel<1, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(ceil_div(C, kThreads)), dim3(kThreads), 0, st, part, ge, gamma, stats,
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(ceil_div(C, 32)), dim3(kThreads), 0, st, part, ge, gamma, stats,
                      coef3, dgamma, dbeta, acc);
   const int64_t total = (int64_t)N * ge.HW * ge.C8;
   int grid = (int)((total + kThreads - 1) / kThreads);
