@@ -39,6 +39,13 @@ def main():
             cells.append("%s:%.0f(%.0f)" % (tile, us, gflop / us * 1e3))
             best = min(best, us)
         os.environ.pop("TDN_WGRAD_TILE", None)
+        os.environ["TDN_WGRAD9"] = "0"
+        us_t1 = timeit(lambda: ops.conv2d_wgrad(x, g, w, k, s, k // 2), args.iters)
+        os.environ["TDN_WGRAD9"] = "1"
+        us_t9 = timeit(lambda: ops.conv2d_wgrad(x, g, w, k, s, k // 2), args.iters)
+        os.environ.pop("TDN_WGRAD9", None)
+        cells.append("tap-per-tile:%.0f nine-tap:%.0f" % (us_t1, us_t9))
+        tot["tap-per-tile"] = tot.get("tap-per-tile", 0) + us_t1 * cnt
         us_auto = timeit(lambda: ops.conv2d_wgrad(x, g, w, k, s, k // 2), args.iters)
         tot["auto"] = tot.get("auto", 0) + us_auto * cnt
         tot["best"] = tot.get("best", 0) + best * cnt

@@ -145,9 +145,18 @@ def test_conv_epilogue_up2x_and_sumpool(ops):
         ops.conv2d_fwd(nhwc(x), pack_w(w), 1, 1, 0, None, None, nhwc(det_tensor((N, C, 3, 6), 1)), ops.ADD_UP2X)
 
 
-@pytest.mark.parametrize("case", CONV_CASES + [(2, 40, 48, 64, 64, 3, 1), (2, 16, 16, 512, 512, 3, 1)])
+# the nine-tap wgrad kernel (3x3 / stride 1 / pad 1, Cout % 128 == 0): odd widths, several images, pixel counts that
+# are not multiples of the 64-pixel K-step, single- and multi-split plans
+T9_CASES = [(3, 13, 21, 128, 128, 3, 1), (2, 40, 48, 64, 256, 3, 1), (1, 7, 7, 192, 384, 3, 1),
+            (2, 25, 42, 512, 512, 3, 1), (1, 3, 70, 64, 128, 3, 1), (5, 2, 8, 64, 128, 3, 1), (3, 5, 9, 64, 128, 3, 1),
+            (1, 9, 64, 64, 128, 3, 1), (1, 6, 65, 64, 128, 3, 1), (1, 7, 63, 64, 128, 3, 1)]
+
+
+@pytest.mark.parametrize("case", CONV_CASES + [(2, 40, 48, 64, 64, 3, 1), (2, 16, 16, 512, 512, 3, 1)] + T9_CASES)
 @pytest.mark.parametrize("bn", [True, False])
-def test_conv_wgrad(ops, case, bn):
+def test_conv_wgrad(ops, case, bn, monkeypatch):
+    if case in T9_CASES:
+        monkeypatch.setenv("TDN_WGRAD9", "1")   # the plan would pick the tap-per-tile kernel at these small sizes
     N, H, W, Cin, Cout, k, s = case
     Ho, Wo = ops.conv_out_size(H, k, s, k // 2), ops.conv_out_size(W, k, s, k // 2)
     x = det_tensor((N, Cin, H, W), 31, -1, 1)
@@ -403,6 +412,12 @@ def test_full_size_layers(ops, shape, monkeypatch):
     # wgrad at full size: the column sums (dbeta) are an exact-able checksum — sum of g over all pixels
     dw, _, db = ops.conv2d_wgrad(x, gg, w, k, s, k // 2)
     assert rel_l2(db.cpu(), gg.float().sum((0, 1, 2)).cpu()) <= 1e-4
+    # the nine-tap kernel (the plan's choice for the big 3x3 layers) and the tap-per-tile kernel are two fp32
+    # accumulations of the same bf16 products: they may differ only by summation order
+    monkeypatch.setenv("TDN_WGRAD9", "0")
+    dw_t1, _, db_t1 = ops.conv2d_wgrad(x, gg, w, k, s, k // 2)
+    monkeypatch.delenv("TDN_WGRAD9")
+    assert rel_l2(dw, dw_t1) <= 1e-5 and rel_l2(db, db_t1) <= 1e-5
     # and the weight gradient against a CPU einsum on a channel sample (full K = all pixels)
     co, ci = [0, Cout // 2, Cout - 1], [0, Cin - 1]
     gs = gg.float().cpu()[..., co]                                    # N,Ho,Wo,3

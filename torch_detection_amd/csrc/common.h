@@ -95,6 +95,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
   __builtin_amdgcn_global_load_lds((const TDN_GLOBAL void*)gsrc, (TDN_LDS void*)lds_base, 16, 0, 0);
 }
 
+// The same copy issued through inline asm, for loops that prefetch stage t+1 while they still read stage t.  The
+// compiler treats the builtin above as an LDS store that any later ds_read may alias and puts `s_waitcnt vmcnt(0)` in
+// front of the first such read, i.e. it waits for the prefetch it has just issued.  Hidden in asm, the copy is ordered
+// by the kernel's own `s_waitcnt vmcnt` + `s_barrier` only.  `lds_base` must be wave-uniform.
+__device__ __forceinline__ void glds16_async(const void* gsrc, void* lds_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned lds_addr = (unsigned)(size_t)(TDN_LDS char*)lds_base;
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+               :: "v"((const TDN_GLOBAL void*)gsrc), "s"(lds_addr) : "memory");   // m0 is reserved: the compiler never keeps a value in it across statements
+#endif
+}
+
 __device__ __forceinline__ bf16x8_t lds_read_b128(const void* p) {
   return *(const TDN_LDS bf16x8_t*)((const TDN_LDS char*)p);
 }
