@@ -575,8 +575,10 @@ static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps, bool grouped =
     // where the weight gradients run on side streams next to the dgrad chain, taking it for every eligible layer was
     // still the fastest of three settings in each of three back-to-back rounds (380.9 off / 383.6 large layers only /
     // 386.3 img/s always), so eligibility alone decides.  TDN_WGRAD9=0 turns the kernel off.
-    const char* env = getenv("TDN_WGRAD9");
-    w.t9 = env ? (atoi(env) != 0) : 1;
+    const char* env = getenv("TDN_WGRAD9");   // 0: off, 1: every eligible layer, 2: only layers with >= 256 units of work
+    const int mode = env ? atoi(env) : 1;
+    const int64_t units = (int64_t)ceil_div(M, 512) * (Cout / 128) * (Ktap / 64);
+    w.t9 = mode == 2 ? (units >= 256) : (mode != 0);
   }
   // measured (scripts/wgrad_bench.py): 64-wide ci tiles beat 128; 256-wide co tiles (8 waves) win when Cout allows,
   // except for the small-M 3x3 layers where the extra workgroups of the 128-wide tile matter more
@@ -605,7 +607,7 @@ static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps, bool grouped =
   // workgroup writes a full fp32 tile slab, so short splits turn the kernel (and the finalize pass that re-reads
   // the slabs) into an HBM-bound slab copy.
   int target = w.t9 ? 256 : 512, min_chunk = 512;   // the nine-tap kernel holds 150 KB of LDS: one per CU
-  if (const char* env = getenv("TDN_WGRAD_WGS")) target = atoi(env) > 0 ? atoi(env) : target;
+  if (const char* env = getenv(w.t9 ? "TDN_WGRAD9_WGS" : "TDN_WGRAD_WGS")) target = atoi(env) > 0 ? atoi(env) : target;
   if (const char* env = getenv("TDN_WGRAD_MINCHUNK")) min_chunk = atoi(env) > 0 ? atoi(env) : min_chunk;
   int splitk = ceil_div(target, tiles);
   const int max_split = ceil_div(M, min_chunk) > 0 ? ceil_div(M, min_chunk) : 1;

@@ -322,6 +322,75 @@ def join_side_stream(device):
         cur = torch.cuda.current_stream(device)
         for st in pool:
             cur.wait_stream(st)
+    used = _branch_used.pop(key, None)
+    if used:
+        cur = torch.cuda.current_stream(device)
+        for st in used:
+            cur.wait_stream(st)
+    _side_refs.pop(key, None)
+
+
+# Independent branches of the forward / dgrad chain (a block's downsample conv beside conv1 -> conv2, its dgrad beside
+# the conv3 -> conv2 dgrads, the small FPN output convs beside the lateral chain, the lateral dgrads beside the output
+# convs' dgrad chain) run on two streams of their own — not the weight-gradient pool, where they would queue behind long
+# wgrad kernels.  Most of these launches cannot fill 256 CUs alone.  TDN_BRANCH=0 keeps everything on the main stream.
+_branch_streams = {}
+_branch_used = {}     # streams forked since the last join (a capture must not wait on a stream it never forked)
+_branch_rr = [0]
+
+
+class branch(object):
+    """``with branch(dev, unit, keep=(tensors...)) as br: y = unit_fwd(...)`` runs the enclosed library launches on a
+    branch stream that first waits for everything enqueued on the current stream; ``br.join()`` makes the current
+    stream wait for them.  Outputs are allocated on the current stream as usual (only the kernels move), ``keep``
+    lists the operands whose memory must outlive the branch kernels.  Units with a run-time norm (GroupNorm, BN in
+    training mode) involve PyTorch ops on the current stream and stay inline."""
+
+    def __init__(self, device, unit=None, keep=()):
+        self.side = None
+        n = int(os.environ.get('TDN_BRANCH', '2'))
+        if n <= 0 or (unit is not None and (unit.gn or unit.bnt)):
+            return
+        key = (device.index, torch._C._cuda_getCurrentRawStream(device.index))
+        pool = _branch_streams.get(key)
+        if pool is None or len(pool) != n:
+            pool = [torch.cuda.Stream(device=device) for _ in range(n)]
+            _branch_streams[key] = pool
+        _branch_rr[0] = (_branch_rr[0] + 1) % n
+        self.side = pool[_branch_rr[0]]
+        self.key, self.keep, self.device = key, keep, device
+
+    def __enter__(self):
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(ev)
+            _side_refs.setdefault(self.key, []).extend(self.keep)
+            _branch_used.setdefault(self.key, set()).add(self.side)
+            self.prev = _lib.set_stream_override(self.side.cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            _lib.set_stream_override(self.prev)
+            self.done = torch.cuda.Event()
+            self.done.record(self.side)
+        return False
+
+    def join(self):
+        if self.side is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.done)
+
+
+def join_branches(device):
+    """End of a forward pass: nothing of it may still be running on a branch stream; operands kept alive for the
+    branches are released."""
+    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index))
+    used = _branch_used.pop(key, None)
+    if used:
+        cur = torch.cuda.current_stream(device)
+        for st in used:
+            cur.wait_stream(st)
     _side_refs.pop(key, None)
 
 
@@ -465,14 +534,20 @@ class SeqNet(object):
 
 
 def _block_fwd(x, b):
+    res, br = x, None
+    if b.ud is not None:
+        with branch(x.device, b.ud, (x,)) as br:    # the downsample conv runs beside conv1 (-> conv2)
+            res = unit_fwd(b.ud, x, relu=False)
     if b.kind == 'bottleneck':
         h1 = unit_fwd(b.u1, x, relu=True)
         h2 = unit_fwd(b.u2, h1, relu=True)
-        res = x if b.ud is None else unit_fwd(b.ud, x, relu=False)
+        if br is not None:
+            br.join()
         out = unit_fwd(b.u3, h2, res, ADD_SAME, True)
         return out, (x, h1, h2, out)
     h1 = unit_fwd(b.u1, x, relu=True)
-    res = x if b.ud is None else unit_fwd(b.ud, x, relu=False)
+    if br is not None:
+        br.join()
     out = unit_fwd(b.u2, h1, res, ADD_SAME, True)
     return out, (x, h1, None, out)
 
@@ -484,6 +559,10 @@ def _block_bwd(b, saved, g, extra, mask_src, need_dx):
     block that produced this block's input.  Returns (dx | None, {unit: grads})."""
     x, h1, h2, out = saved
     grads = {}
+    t, br = None, None
+    if need_dx and b.ud is not None:
+        with branch(g.device, b.ud, (g, extra) if extra is not None else (g,)) as br:
+            t = unit_dgrad(b.ud, g, _hw(x), extra, ADD_SAME)   # beside the conv3 -> conv2 dgrads of the main path
     if b.kind == 'bottleneck':
         grads[b.u3] = unit_wgrad(b.u3, h2, g)
         g2 = unit_dgrad(b.u3, g, _hw(h2), mask_src=h2)
@@ -498,7 +577,7 @@ def _block_bwd(b, saved, g, extra, mask_src, need_dx):
     dx = None
     if need_dx:
         if b.ud is not None:
-            t = unit_dgrad(b.ud, g, _hw(x), extra, ADD_SAME)
+            br.join()
         elif extra is not None:
             t = ops.add_relu_mask(g, extra, None)
         else:
@@ -555,6 +634,7 @@ class SeqNetFunction(torch.autograd.Function):
                 outs.append(cur)
         if not net.blocks:
             outs.append(cur)
+        join_branches(cur.device)
         ctx.net, ctx.st, ctx.saved, ctx.dev = net, st, saved, cur.device
         if DEBUG_CAPTURE is not None:
             DEBUG_CAPTURE['seq'] = (st, saved)
@@ -638,13 +718,19 @@ class FPNFunction(torch.autograd.Function):
         inputs = args[:net.num_ins]
         nlat = len(net.lat)
         xs = [ops.to_nhwc_bf16(inputs[i + net.start_level], net.dtype) for i in range(nlat)]
-        lat = [None] * nlat
+        lat, outs = [None] * nlat, [None] * nlat
         for i in reversed(range(nlat)):
             if i == nlat - 1:
                 lat[i] = unit_fwd(net.lat[i], xs[i])
             else:
                 lat[i] = unit_fwd(net.lat[i], xs[i], lat[i + 1], ADD_UP2X)
-        outs = [unit_fwd(net.fpn[i], lat[i]) for i in range(nlat)]
+            if i > 0:
+                # the coarse levels' output convs (small launches) run beside the rest of the top-down chain
+                with branch(lat[i].device, net.fpn[i], (lat[i],)):
+                    outs[i] = unit_fwd(net.fpn[i], lat[i])
+            else:
+                outs[i] = unit_fwd(net.fpn[i], lat[i])
+        join_branches(lat[0].device)
         extra_in = []   # inputs of the extra stride-2 convs (RetinaNet style), for backward
         if net.num_outs > nlat:
             if not net.add_extra_convs:
@@ -706,11 +792,16 @@ class FPNFunction(torch.autograd.Function):
             gi = d[i] if d[i] is not None else zeros(i)
             unit_grads[net.fpn[i]] = unit_wgrad(net.fpn[i], lat[i], gi)
             dL[i] = unit_dgrad(net.fpn[i], gi, _hw(lat[i]), dL[i - 1] if i > 0 else None, ADD_SUMPOOL2)
-        for i in range(nlat):
+            # level i's lateral gradients need only dL[i]: they run beside the remaining (coarser, smaller) output
+            # convs' dgrad chain; the coarsest one, whose result the backbone's backward starts from, stays inline
             unit_grads[net.lat[i]] = unit_wgrad(net.lat[i], xs[i], dL[i])
             k = i + net.start_level
             if ctx.needs_input_grad[1 + k]:
-                t = unit_dgrad(net.lat[i], dL[i], _hw(xs[i]), dx[k], ADD_SAME)
+                if i < nlat - 1:
+                    with branch(dev, net.lat[i], (dL[i], dx[k]) if dx[k] is not None else (dL[i],)):
+                        t = unit_dgrad(net.lat[i], dL[i], _hw(xs[i]), dx[k], ADD_SAME)
+                else:
+                    t = unit_dgrad(net.lat[i], dL[i], _hw(xs[i]), dx[k], ADD_SAME)
                 dx[k] = t
         flat = []
         for u in net.units():
