@@ -359,6 +359,37 @@ def test_graphed_step_matches_eager(T):
     assert all(torch.equal(p.grad, g) for p, g in zip(params, got_g))
 
 
+@pytest.mark.parametrize("depth", [18, 50])
+def test_branch_streams_change_nothing(T, depth, monkeypatch):
+    """functional.branch moves independent launches (downsample conv / dgrad, coarse FPN output convs, lateral dgrads)
+    to streams of their own: outputs and every gradient must equal the single-stream run bit for bit, repeatedly
+    (a missing dependency would show up as run-to-run differences)."""
+    m = T.ResNet(depth).cuda().train()
+    m.init_weights()
+    chans = [64, 128, 256, 512] if depth == 18 else [256, 512, 1024, 2048]
+    neck = T.FPN(chans, 256, 5).cuda()
+    neck.init_weights()
+    x = det_tensor((2, 3, 96, 160), 11, -1, 1).cuda()
+    params = list(m.parameters()) + list(neck.parameters())
+
+    def run():
+        for p in params:
+            p.grad = None
+        o = neck(m(x))
+        torch.autograd.backward(o, [det_tensor(tuple(t.shape), 30 + i, -1, 1).cuda().to(t.dtype)
+                                    for i, t in enumerate(o)])
+        torch.cuda.synchronize()
+        return [t.clone() for t in o], [p.grad.clone() for p in params]
+
+    monkeypatch.setenv("TDN_BRANCH", "0")
+    ref_o, ref_g = run()
+    monkeypatch.setenv("TDN_BRANCH", "2")
+    for _ in range(3):
+        o, g = run()
+        assert all(torch.equal(a, b) for a, b in zip(o, ref_o))
+        assert all(torch.equal(a, b) for a, b in zip(g, ref_g))
+
+
 def test_dilated_resnet_vs_golden(T, manifest, golden_dir):
     """ResNet(strides=(1,2,1,1), dilations=(1,1,2,4)) forward against the reference golden (R18) and the oracle (R50),
     plus a backward pass through the dilated stages."""
