@@ -234,7 +234,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
 //   * three x windows, one per vertical tap offset dh: the 66 consecutive input pixels  m0 + dh*W - 1 ... m0 + dh*W + 64
 //     (in NHWC the neighbour (h+dh, w+dw) of flattened pixel m is pixel m + dh*W + dw), rows above / below the image
 //     read from the zero page; tap (dh, dw) reads its fragments from window dh at a row offset of 1 + dw.
-// 43 KB of LDS-DMA per K-step (two stages: 86 KB of LDS, one workgroup per CU) feed 9 x 128 x 64 x 64 MACs (219 flop/B against 51 for the 256x64 single-tap tile).
+// 43 KB of LDS-DMA per K-step (two stages: 86 KB of LDS, one workgroup per CU) feed 9 x 128 x 64 x 64 MACs: 219 flop/B
+// against 51 for the 256x64 single-tap tile.
 // Needs W >= 8 (at most one line end per 8 consecutive pixels).  Slab layout and finalize pass are unchanged:
 // slab[split][co][tap*Cin + ci].
 template <bool F16>
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BKW = 64, BMW = 128, BNW = 64;
   constexpr int RBG = BMW * 2, RBX = BNW * 2;                 // 256 / 128 bytes per row
-  constexpr int G_TILE = BKW * RBG;                           // 16 KB per dw variant
+  constexpr int G_TILE = BKW * RBG;                           // 16 KB
   constexpr int XROWS = 72;                                   // 66 used
   constexpr int X_TILE = XROWS * RBX;                         // 9 KB per dh window
   constexpr int STAGE = G_TILE + 3 * X_TILE;                  // 43 KB
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9_kernel(const WgradParams p) {
   const int W = p.Wo, H = p.Ho;            // stride 1, pad 1: input and output grids coincide
   const bf16_t* zero = (const bf16_t*)g_zero_page;
 
-  // ---- loader state: g rows (2 per lane and dw variant), x rows (2 per lane and dh window) ----
+  // ---- loader state: 2 g rows per lane; per dh window 1 x row per lane (+ rows 64..71 from wave 0) ----
   const int g_lrow = lane >> 4, g_pc = lane & 15;             // 4 rows x 16 chunks per piece
   const int x_lrow = lane >> 3, x_pc = lane & 7;              // 8 rows x 8 chunks per piece
   const int g_row0 = wave * 4 + g_lrow;                       // + it*32
