@@ -290,12 +290,14 @@ _side_rr = [0]
 
 
 def _num_side_streams():
-    return max(0, int(os.environ.get('TDN_SIDE_STREAM', '4')))
+    return max(0, int(os.environ.get('TDN_SIDE_STREAM', '8')))
 
 
 def _side_stream(device):
-    """Next side stream (round robin over TDN_SIDE_STREAM streams, default 4; 0 disables) for this device /
-    main stream."""
+    """Next side stream (round robin over TDN_SIDE_STREAM streams, default 8; 0 disables) for this device /
+    main stream.  Keep the count a multiple of 4: the runtime deals streams onto 4 hardware queues, and whole-step
+    A/B runs with 5 or 7 streams were 5-8 % slower than with 4 or 8 (8: equal to +1.6 % depending on the box);
+    raising GPU_MAX_HW_QUEUES to 8 or 16 cost 35 %."""
     n = _num_side_streams()
     if n == 0:
         return None
