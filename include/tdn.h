@@ -48,7 +48,8 @@ enum {
 /* Fused epilogue applied to the fp32 accumulator of a conv / dgrad GEMM:
  *   v = acc * scale[c] + shift[c]          (eval-mode BatchNorm2d folded, layers.py:50-54; or conv bias, layers.py:93)
  *   v += addend(...)                        (see modes above)
- *   if relu:      v = max(v, 0)             (nn.ReLU, resnet.py:35,90,217)
+ *   if relu:      v = max(v, 0)             (nn.ReLU, resnet.py:35,90,217); relu == 2: v = min(v, 6) as well
+ *                                           (nn.ReLU6, layers.py:117-118), values under 6 stay under 6 when stored
  *   if mask_src:  v = mask_src > 0 ? v : 0  (adjoint of that ReLU, from the saved forward output)
  *   out = (bf16) v          (or fp32 when out_f32 != 0: pre-rounding value, used for 1e-3 parity checks
  *                             and for fp32 module outputs)
@@ -60,7 +61,7 @@ typedef struct tdn_epilogue {
   int32_t addend_mode;   /* TDN_ADD_* */
   int32_t addend_h;      /* spatial size of the addend tensor (UP2X / SUMPOOL2) */
   int32_t addend_w;
-  int32_t relu;          /* 0 / 1 */
+  int32_t relu;          /* 0 none / 1 ReLU / 2 ReLU6 */
   const void* mask_src;  /* NHWC, same shape as the output, or NULL */
   int32_t out_f32;       /* 0: out is bf16 NHWC; 1: out is float32 NHWC */
   int32_t reserved;
@@ -188,6 +189,24 @@ int tdn_add_relu_mask(const void* a, const void* b, const void* mask_src, void* 
                       int dtype, void* stream);
 
 /* bf16 NHWC <-> fp32 NCHW (logical, element strides) boundary converters. */
+/* ConvModule activation / pre-activation pieces (models/utils/layers.py:57-135: activation='relu6',
+ * activate_last=False).  tdn_clamp_max: y = min(y, hi) in place (the upper clamp of nn.ReLU6 after a ReLU epilogue).
+ * tdn_act_mask: out = g where 0 < y < hi, else 0 — the activation's backward from its saved OUTPUT y (hi = +inf:
+ * ReLU, 6: ReLU6).  n % 8 == 0. */
+int tdn_clamp_max(void* y, float hi, int64_t n, int dtype, void* stream);
+int tdn_act_mask(const void* g, const void* y, void* out, float hi, int64_t n, int dtype, void* stream);
+/* Pre-activation order (layers.py:129-134: norm -> activate -> conv): BatchNorm2d in eval mode on the conv's INPUT,
+ * folded to y = act(x * scale[c] + shift[c]) (tdn_bn_fold), act 0 none / 1 ReLU / 2 ReLU6; NHWC [npix][C], C % 8 == 0.
+ * Backward, from g = dL/dy already masked by the activation (tdn_act_mask): dx = g * scale[c],
+ * dbeta[c] = sum g, dgamma[c] = invstd[c] * sum g * (x - mean[c]); beta != 0 accumulates into dgamma / dbeta.
+ * Deterministic (per-chunk partial sums in the workspace, added in order). */
+int tdn_channel_affine_fwd(const void* x, const float* scale, const float* shift, void* y, int64_t npix, int C,
+                           int act, int dtype, void* stream);
+int64_t tdn_channel_affine_bwd_workspace(int64_t npix, int C);
+int tdn_channel_affine_bwd(const void* g, const void* x, const float* scale, const float* mean, const float* invstd,
+                           void* dx, float* dgamma, float* dbeta, float beta, int64_t npix, int C, void* workspace,
+                           int64_t workspace_bytes, int dtype, void* stream);
+
 int tdn_nchw_f32_to_nhwc(const float* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w,
                          int N, int C, int H, int W, void* dst, int dtype, void* stream);
 int tdn_nhwc_to_nchw_f32(const void* src, int N, int C, int H, int W, float* dst, int dtype,
@@ -225,6 +244,7 @@ int tdn_bbox_denormalize(const float* bbox, float* out, int64_t rows, int cols, 
  * nn.GroupNorm(get_group_gn(planes), planes) — models/utils/layers.py:50-54,138-154 (32 groups, eps 1e-5, biased
  * variance) — after a conv of ResNet(use_gn=True) (models/backbone/resnet.py:42-59,97-119,254-257) or of a
  * ConvModule with GN (layers.py:122-135), fused with the residual add and ReLU that follow it.
+ *   (relu: 0 none, 1 ReLU, 2 ReLU6 — as in the conv epilogue; the same for tdn_bn_train_fwd)
  *   tdn_gn_fwd: z (N,H,W,C) raw conv output -> y = relu?((z - mu) * rstd * gamma + beta (+ addend)); addend_mode
  *               TDN_ADD_SAME (same shape: the residual) or TDN_ADD_UP2X ((N,H/2,W/2,C): FPN top-down, fpn.py:98-100);
  *               stats (N,C,2) float = per-channel (mu, rstd) of the channel's group, kept for the backward.

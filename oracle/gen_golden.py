@@ -11,7 +11,9 @@ Run:  python oracle/gen_golden.py
 """
 import collections
 import collections.abc
+import contextlib
 import json
+import warnings
 import os
 import sys
 import types
@@ -473,6 +475,59 @@ def main():
     man["bn_train_r18"] = {"state_seed": 2200, "input": {"shape": [2, 3, 64, 96], "seed": 2210, "lo": -2.0, "hi": 2.0},
                            "cot_seed0": 2220, "grad_keys": keep, "out_shapes": [list(o.shape) for o in outs],
                            "num_batches_tracked_after": int(new_sd["bn1.num_batches_tracked"])}
+
+    # ---- ConvModule: ReLU6 and the pre-activation order (layers.py:57-135), forward + all gradients ---------------
+    from models.utils.layers import ConvModule as RefConvModule
+    cm = {}
+    cm_cases = [
+        # tag, kernel, bias, normalize, use_gn, activation, activate_last, training
+        ("post_bn_relu6", 3, False, True, False, "relu6", True, False),
+        ("post_bias_relu6", 3, True, False, False, "relu6", True, False),
+        ("post_gn_relu6", 1, False, True, True, "relu6", True, False),
+        ("pre_bn_relu", 3, True, True, False, "relu", False, False),
+        ("pre_bn_relu6_train", 3, True, True, False, "relu6", False, True),
+        ("pre_gn_relu6", 3, True, True, True, "relu6", False, False),
+        ("pre_none_relu", 1, True, False, False, "relu", False, False),
+        ("pre_bn_noact", 3, False, True, False, None, False, False),
+    ]
+    man["conv_module"] = {"input": {"shape": [2, 64, 12, 16], "lo": -8.0, "hi": 8.0}, "cases": []}
+    for ci, (tag, k, bias, norm, use_gn, actv, last, training) in enumerate(cm_cases):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = RefConvModule(64, 64, k, padding=k // 2, bias=bias, normalize=dict() if norm else None, use_gn=use_gn,
+                              activation=actv, activate_last=last)
+        sd = fill_state_dict(m.state_dict(), 2600 + 10 * ci)
+        m.load_state_dict(sd)
+        m.train(training)
+        x = det_tensor((2, 64, 12, 16), 2601 + 10 * ci, -8.0, 8.0).requires_grad_(True)
+        y = m(x * 1.0)   # a non-leaf input: the reference's in-place activations refuse a leaf that requires grad
+        cot = det_tensor(tuple(y.shape), 2602 + 10 * ci, -1.0, 1.0)
+        y.backward(cot)
+        ps = {k_: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k_)
+              for k_, v in sd.items()}
+        x2 = x.detach().clone().requires_grad_(True)
+        ctxm = O.bn_training() if training else contextlib.nullcontext()
+        with ctxm:
+            y2 = O.conv_module_forward(ps, x2, 1, k // 2, actv, last)
+        y2.backward(cot)
+        assert torch.equal(y, y2), "oracle != reference (ConvModule %s forward)" % tag
+        assert torch.equal(x.grad, x2.grad), "oracle != reference (ConvModule %s dx)" % tag
+        for k_, p_ in m.named_parameters():
+            assert torch.equal(ps[k_].grad, p_.grad), "oracle != reference (ConvModule %s grad %s)" % (tag, k_)
+        cm[tag + "/y"] = y.detach().numpy()
+        cm[tag + "/dx"] = x.grad.numpy()
+        for k_, p_ in m.named_parameters():
+            cm[tag + "/grad/" + k_] = p_.grad.numpy()
+        if training:
+            new_sd = m.state_dict()
+            for k_ in ("norm.running_mean", "norm.running_var"):
+                assert torch.equal(ps[k_], new_sd[k_]), "oracle != reference (ConvModule %s %s)" % (tag, k_)
+                cm[tag + "/stat/" + k_] = new_sd[k_].numpy()
+        man["conv_module"]["cases"].append({"tag": tag, "kernel": k, "bias": bias, "normalize": norm,
+                                            "use_gn": use_gn, "activation": actv, "activate_last": last,
+                                            "training": training, "state_seed": 2600 + 10 * ci,
+                                            "input_seed": 2601 + 10 * ci, "cot_seed": 2602 + 10 * ci})
+    np.savez_compressed(os.path.join(GOLD, "conv_module.npz"), **cm)
 
     # ---- image batch staging: normalize -> flip -> pad to /32 -> CHW -> collate ------------
     from datasets.utils.image import img_flip, img_normalize, img_pad_size_divisor

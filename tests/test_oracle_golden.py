@@ -344,3 +344,37 @@ def test_bn_training_oracle_vs_reference_golden(manifest, golden_dir):
         assert np.array_equal(ps[k].grad.numpy(), gold["grad/" + k]), k
     for k in ("bn1.running_mean", "bn1.running_var", "layer4.1.bn2.running_mean", "layer4.1.bn2.running_var"):
         assert np.array_equal(ps[k].detach().numpy(), gold["stat/" + k]), k
+
+
+def test_conv_module_oracle_vs_reference_golden(manifest, golden_dir):
+    """ConvModule with ReLU6 and in the pre-activation order (layers.py:57-135): the oracle reproduces the reference's
+    output, input gradient, every parameter gradient and (training-mode BN) the updated running statistics."""
+    import contextlib
+    from oracle import torch_ref as O
+    import torch_detection_amd as T
+    torch.set_num_threads(4)
+    meta = manifest["conv_module"]
+    gold = np.load(os.path.join(golden_dir, "conv_module.npz"))
+    i = meta["input"]
+    for c in meta["cases"]:
+        tag, k = c["tag"], c["kernel"]
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = T.ConvModule(64, 64, k, padding=k // 2, bias=c["bias"], normalize=dict() if c["normalize"] else None,
+                             use_gn=c["use_gn"], activation=c["activation"], activate_last=c["activate_last"])
+        sd = fill_state_dict(m.state_dict(), c["state_seed"])
+        ps = {k_: v.clone().requires_grad_(v.is_floating_point() and "running" not in k_) for k_, v in sd.items()}
+        x = det_tensor(tuple(i["shape"]), c["input_seed"], i["lo"], i["hi"]).requires_grad_(True)
+        with (O.bn_training() if c["training"] else contextlib.nullcontext()):
+            y = O.conv_module_forward(ps, x, 1, k // 2, c["activation"], c["activate_last"])
+        y.backward(det_tensor(tuple(y.shape), c["cot_seed"], -1, 1))
+        assert np.array_equal(y.detach().numpy(), gold[tag + "/y"]), tag
+        assert np.array_equal(x.grad.numpy(), gold[tag + "/dx"]), tag
+        for k_, v in ps.items():
+            if v.requires_grad:
+                assert np.array_equal(v.grad.numpy(), gold[tag + "/grad/" + k_]), (tag, k_)
+        if c["training"]:
+            for k_ in ("norm.running_mean", "norm.running_var"):
+                assert np.array_equal(ps[k_].detach().numpy(), gold[tag + "/stat/" + k_]), (tag, k_)
+

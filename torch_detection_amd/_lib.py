@@ -62,6 +62,11 @@ SIGNATURES = {
     "tdn_subsample2_fwd": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "tdn_subsample2_bwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "tdn_add_relu_mask": (c_int, [c_void_p] * 4 + [c_i64, c_int, c_void_p]),
+    "tdn_clamp_max": (c_int, [c_void_p, c_float, c_i64, c_int, c_void_p]),
+    "tdn_act_mask": (c_int, [c_void_p] * 3 + [c_float, c_i64, c_int, c_void_p]),
+    "tdn_channel_affine_fwd": (c_int, [c_void_p] * 4 + [c_i64, c_int, c_int, c_int, c_void_p]),
+    "tdn_channel_affine_bwd_workspace": (c_i64, [c_i64, c_int]),
+    "tdn_channel_affine_bwd": (c_int, [c_void_p] * 8 + [c_float, c_i64, c_int, c_void_p, c_i64, c_int, c_void_p]),
     "tdn_nchw_f32_to_nhwc": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p,
                                      c_int, c_void_p]),
     "tdn_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

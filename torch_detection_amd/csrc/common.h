@@ -90,6 +90,15 @@ __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// Upper knee of nn.ReLU6 for a value about to be stored in the 16-bit element type: 6 from 6 up, and below 6 never
+// more than the largest element value under 6 (bf16 5.96875, fp16 5.99609375) — rounding to nearest would otherwise
+// turn (5.984, 6) into 6.0, and the backward pass, which reads the mask 0 < y < 6 from the stored output, would drop
+// those elements' gradients.
+template <bool F16>
+__device__ __forceinline__ float relu6_top(float v) {
+  return v >= 6.f ? 6.f : fminf(v, F16 ? 5.99609375f : 5.96875f);
+}
+
 // 16-byte async global -> LDS copy. LDS destination = wave-uniform `lds_base` + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
   __builtin_amdgcn_global_load_lds((const TDN_GLOBAL void*)gsrc, (TDN_LDS void*)lds_base, 16, 0, 0);

@@ -579,6 +579,12 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
         for (int i = 0; i < FN; ++i)
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
+        if (p.relu == 2) {
+#pragma unroll
+          for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = relu6_top<F16>(v[i][e]);
+        }
       }
       if (p.mask) {
 #pragma unroll
@@ -629,6 +635,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
         if (p.relu) {
   #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          if (p.relu == 2) {
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = relu6_top<F16>(v[e]);
+          }
         }
         if (p.mask) {
           const f32x4_t mk = load4_f32<F16>(p.mask + opix * p.Cout + ch);

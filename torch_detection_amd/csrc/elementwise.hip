@@ -394,6 +394,189 @@ extern "C" int tdn_add_relu_mask(const void* a, const void* b, const void* mask_
   return 0;
 }
 
+// ---- ConvModule activation / pre-activation pieces (layers.py:57-135 of the reference) ----------------
+// ReLU6 (nn.ReLU6 = hardtanh(0, 6)): the conv epilogues clamp at 0; the upper clamp and the backward mask
+// (gradient passes where 0 < y < hi, read from the saved OUTPUT) are these two element-wise passes.
+template <bool F16>
+__global__ void clamp_max_kernel(bf16_t* y, float hi, int64_t n8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    bf16x8_t v = *(const bf16x8_t*)(y + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f32_to_elem<F16>(fminf(elem_to_f32<F16>(v[e]), hi));
+    *(bf16x8_t*)(y + i * 8) = v;
+  }
+}
+
+extern "C" int tdn_clamp_max(void* y, float hi, int64_t n, int dtype, void* stream) {
+  TDN_CHECK_DTYPE(dtype);
+  TDN_CHECK(y && n > 0 && n % 8 == 0, "tdn_clamp_max: bad arguments (n=%lld)", (long long)n);
+  TDN_LAUNCH_T(clamp_max_kernel, dtype, dim3(grid_for(n / 8, 256)), dim3(256), (hipStream_t)stream, (bf16_t*)y, hi,
+               n / 8);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool F16>
+__global__ void act_mask_kernel(const bf16_t* g, const bf16_t* y, bf16_t* out, float hi, int64_t n8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const bf16x8_t vg = *(const bf16x8_t*)(g + i * 8);
+    const bf16x8_t vy = *(const bf16x8_t*)(y + i * 8);
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = elem_to_f32<F16>(vy[e]);
+      o[e] = (t > 0.f && t < hi) ? vg[e] : f32_to_elem<F16>(0.f);
+    }
+    *(bf16x8_t*)(out + i * 8) = o;
+  }
+}
+
+extern "C" int tdn_act_mask(const void* g, const void* y, void* out, float hi, int64_t n, int dtype, void* stream) {
+  TDN_CHECK_DTYPE(dtype);
+  TDN_CHECK(g && y && out && n > 0 && n % 8 == 0, "tdn_act_mask: bad arguments (n=%lld)", (long long)n);
+  TDN_LAUNCH_T(act_mask_kernel, dtype, dim3(grid_for(n / 8, 256)), dim3(256), (hipStream_t)stream, (const bf16_t*)g,
+               (const bf16_t*)y, (bf16_t*)out, hi, n / 8);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Pre-activation order (activate_last=False): y = act(x * scale[c] + shift[c]) on the conv's INPUT — BatchNorm2d in
+// eval mode folded to a per-channel affine, act = none / ReLU / ReLU6.  NHWC, C % 8 == 0.
+template <bool F16>
+__global__ void channel_affine_kernel(const bf16_t* x, const float* scale, const float* shift, bf16_t* y,
+                                      int64_t n8, int C8, int act) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8) * 8;
+    const bf16x8_t v = *(const bf16x8_t*)(x + i * 8);
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = elem_to_f32<F16>(v[e]) * scale[c + e] + shift[c + e];
+      if (act >= 1) t = fmaxf(t, 0.f);
+      if (act == 2) t = relu6_top<F16>(t);
+      o[e] = f32_to_elem<F16>(t);
+    }
+    *(bf16x8_t*)(y + i * 8) = o;
+  }
+}
+
+extern "C" int tdn_channel_affine_fwd(const void* x, const float* scale, const float* shift, void* y, int64_t npix,
+                                      int C, int act, int dtype, void* stream) {
+  TDN_CHECK_DTYPE(dtype);
+  TDN_CHECK(x && scale && shift && y && npix > 0 && C > 0 && C % 8 == 0 && act >= 0 && act <= 2,
+            "tdn_channel_affine_fwd: bad arguments (npix=%lld C=%d act=%d)", (long long)npix, C, act);
+  const int64_t n8 = npix * (C / 8);
+  TDN_LAUNCH_T(channel_affine_kernel, dtype, dim3(grid_for(n8, 256)), dim3(256), (hipStream_t)stream,
+               (const bf16_t*)x, scale, shift, (bf16_t*)y, n8, C / 8, act);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Backward of the same affine from g = dL/dy already masked by the activation:
+//   dx = g * scale[c];   dbeta[c] = sum_p g;   dgamma[c] = invstd[c] * sum_p g * (x - mean[c])
+// Pass 1: one block per chunk of CHUNK pixels, threads = channel lanes (8 channels each) x pixel lanes, the pixel
+// lanes combined through LDS in lane order, partial sums to the workspace [chunks][2][C].  Pass 2 adds the chunks in
+// order (deterministic).
+static constexpr int kAffineChunk = 512;
+
+template <bool F16>
+__global__ __launch_bounds__(256) void channel_affine_bwd_kernel(const bf16_t* g, const bf16_t* x, const float* scale,
+                                                                 const float* mean, bf16_t* dx, float* partial,
+                                                                 int64_t npix, int C) {
+  __shared__ float red[256 * 16];
+  const int cl = C / 8;                       // channel lanes
+  const int pl = cl >= 256 ? 1 : 256 / cl;    // pixel lanes
+  const int tid = threadIdx.x;
+  const int64_t p0 = (int64_t)blockIdx.x * kAffineChunk;
+  const int64_t p1 = p0 + kAffineChunk < npix ? p0 + kAffineChunk : npix;
+  for (int cbase = 0; cbase < cl; cbase += 256) {   // C > 2048: several rounds of channel lanes
+    const int lane_c = cbase + tid % (cl < 256 ? cl : 256);
+    const int lane_p = tid / (cl < 256 ? cl : 256);
+    const bool active = lane_p < pl && lane_c < cl;
+    float s0[8], s1[8], sc[8], mu[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc[e] = scale[lane_c * 8 + e];
+        mu[e] = mean[lane_c * 8 + e];
+      }
+      for (int64_t p = p0 + lane_p; p < p1; p += pl) {
+        const bf16x8_t vg = *(const bf16x8_t*)(g + (p * cl + lane_c) * 8);
+        const bf16x8_t vx = *(const bf16x8_t*)(x + (p * cl + lane_c) * 8);
+        bf16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gv = elem_to_f32<F16>(vg[e]);
+          s0[e] += gv;
+          s1[e] += gv * (elem_to_f32<F16>(vx[e]) - mu[e]);
+          o[e] = f32_to_elem<F16>(gv * sc[e]);
+        }
+        *(bf16x8_t*)(dx + (p * cl + lane_c) * 8) = o;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[tid * 16 + e] = s0[e];
+      red[tid * 16 + 8 + e] = s1[e];
+    }
+    __syncthreads();
+    if (active && lane_p == 0) {
+      const int w = cl < 256 ? cl : 256;
+      for (int j = 1; j < pl; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s0[e] += red[(j * w + tid) * 16 + e];
+          s1[e] += red[(j * w + tid) * 16 + 8 + e];
+        }
+      float* out = partial + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        out[lane_c * 8 + e] = s0[e];
+        out[C + lane_c * 8 + e] = s1[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void channel_affine_bwd_reduce_kernel(const float* partial, int chunks, int C, const float* invstd,
+                                                 float* dgamma, float* dbeta, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int k = 0; k < chunks; ++k) {
+    s0 += partial[(int64_t)k * 2 * C + c];
+    s1 += partial[(int64_t)k * 2 * C + C + c];
+  }
+  const float dg = s1 * invstd[c];
+  dbeta[c] = beta != 0.f ? beta * dbeta[c] + s0 : s0;
+  dgamma[c] = beta != 0.f ? beta * dgamma[c] + dg : dg;
+}
+
+extern "C" int64_t tdn_channel_affine_bwd_workspace(int64_t npix, int C) {
+  return ((npix + kAffineChunk - 1) / kAffineChunk) * 2 * C * 4;
+}
+
+extern "C" int tdn_channel_affine_bwd(const void* g, const void* x, const float* scale, const float* mean,
+                                      const float* invstd, void* dx, float* dgamma, float* dbeta, float beta,
+                                      int64_t npix, int C, void* workspace, int64_t workspace_bytes, int dtype,
+                                      void* stream) {
+  TDN_CHECK_DTYPE(dtype);
+  TDN_CHECK(g && x && scale && mean && invstd && dx && dgamma && dbeta && workspace && npix > 0 && C > 0 && C % 8 == 0,
+            "tdn_channel_affine_bwd: bad arguments (npix=%lld C=%d)", (long long)npix, C);
+  TDN_CHECK(workspace_bytes >= tdn_channel_affine_bwd_workspace(npix, C), "tdn_channel_affine_bwd: workspace too small");
+  const int chunks = (int)((npix + kAffineChunk - 1) / kAffineChunk);
+  TDN_LAUNCH_T(channel_affine_bwd_kernel, dtype, dim3(chunks), dim3(256), (hipStream_t)stream, (const bf16_t*)g,
+               (const bf16_t*)x, scale, mean, (bf16_t*)dx, (float*)workspace, npix, C);
+  TDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(channel_affine_bwd_reduce_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, chunks, C, invstd, dgamma, dbeta, beta);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- boundary layout converters -----------------------------------------------------------------------
 template <bool F16>
 __global__ void nchw_to_nhwc_kernel(const float* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N,

@@ -6,7 +6,7 @@
 // Unlike eval-mode BatchNorm the statistics depend on the sample, so GN cannot be folded into the conv epilogue:
 //   forward   z = conv(x) (raw, 16-bit)  ->  [1] per-channel partial (sum, sum of squares) over pixel chunks
 //             -> [2] per (sample, group) mean / rstd, expanded to per-(sample, channel) affine (a, b)
-//             -> [3] y = relu?(z*a + b (+ addend))
+//             -> [3] y = relu?(z*a + b (+ addend))      (relu: 0 none, 1 ReLU, 2 ReLU6)
 //   backward  g = dL/dy (ReLU-masked) -> [1'] per-channel partial (sum g, sum g*xhat) -> [2'] dgamma, dbeta and the
 //             per-(sample, channel) coefficients of dz = g*A + z*B + C  ->  [3'] dz, which then feeds the ordinary
 //             conv dgrad / wgrad kernels.
@@ -173,7 +173,11 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ z, const float* __res
     }
     bf16x8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f32_to_elem<F16>(relu ? fmaxf(v[e], 0.f) : v[e]);
+    for (int e = 0; e < 8; ++e) {
+      float t = relu ? fmaxf(v[e], 0.f) : v[e];
+      if (relu == 2) t = relu6_top<F16>(t);       // nn.ReLU6
+      o[e] = f32_to_elem<F16>(t);
+    }
     *(bf16x8_t*)(y + i * 8) = o;
   }
 }

@@ -41,6 +41,7 @@ class ConvUnit(object):
             raise TypeError('expected nn.Conv2d, got %s' % type(conv))
         kh, kw = conv.kernel_size
         self.conv, self.bn, self.relu = conv, bn, relu
+        self.act6 = False       # activation is nn.ReLU6 (ConvModule(activation='relu6')): extra upper clamp at 6
         self.k, self.stride, self.pad = kh, conv.stride[0], conv.padding[0]
         self.Cin, self.Cout = conv.in_channels, conv.out_channels
         self.is_stem = (kh == 7)
@@ -223,6 +224,8 @@ def _gn_store(u):
 
 def unit_fwd(u, x, addend=None, addend_mode=ADD_NONE, relu=None):
     relu = u.relu if relu is None else relu
+    if relu and u.act6:
+        relu = 2                 # nn.ReLU6: the conv epilogue clamps at 6 as well
     if not (u.gn or u.bnt):
         if u.groups > 1:
             return ops.gconv2d_fwd(x, u.w_fwd, u.groups, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode,
@@ -481,7 +484,7 @@ class ConvUnitFunction(torch.autograd.Function):
     @staticmethod
     def _forward(ctx, unit, x, *params):
         xh = ops.to_nhwc_bf16(x, unit.dtype)
-        y = unit_fwd(unit, xh)
+        y = unit_fwd(unit, xh)       # ReLU / ReLU6 fused (relu code 2 for nn.ReLU6, see unit_fwd)
         ctx.unit, ctx.xh, ctx.y = unit, xh, y
         return _as_nchw(y)
 
@@ -495,11 +498,97 @@ class ConvUnitFunction(torch.autograd.Function):
         u = ctx.unit
         g = ops.to_nhwc_bf16(dy, u.dtype)
         if u.relu:
-            g = ops.add_relu_mask(g, None, ctx.y)
+            g = ops.act_mask(g, ctx.y, 6.0) if u.act6 else ops.add_relu_mask(g, None, ctx.y)
         grads = unit_wgrad(u, ctx.xh, g)
         dx = _as_nchw(unit_dgrad(u, g, _hw(ctx.xh))) if ctx.needs_input_grad[1] else None
         join_side_stream(g.device)
         return (None, dx) + tuple(grads)
+
+
+class PreActUnit(object):
+    """ConvModule(activate_last=False) (layers.py:129-134): [norm on the INPUT] -> [ReLU | ReLU6] -> conv (+bias).
+    ``conv`` is the prepared conv(+bias) unit, ``norm`` the nn.BatchNorm2d / nn.GroupNorm over in_channels or None,
+    ``act`` 0 none / 1 ReLU / 2 ReLU6."""
+
+    def __init__(self, conv_unit, norm, act):
+        self.conv, self.norm, self.act = conv_unit, norm, act
+        if norm is not None and not isinstance(norm, (nn.BatchNorm2d, nn.GroupNorm)):
+            raise NotImplementedError('pre-activation norm %s is not on the HIP path' % type(norm).__name__)
+        if isinstance(norm, nn.GroupNorm):
+            C = norm.num_channels
+            if C & (C - 1) or not 64 <= C <= 2048 or not norm.affine:
+                raise NotImplementedError('GroupNorm(%d channels) is not on the HIP path (a power of two in 64..2048)'
+                                          % C)
+        if isinstance(norm, nn.BatchNorm2d) and (not norm.affine or not norm.track_running_stats):
+            raise NotImplementedError('pre-activation BatchNorm2d needs affine=True and running statistics')
+
+    def params(self):
+        p = self.conv.params()
+        if self.norm is not None:
+            p = p + [self.norm.weight, self.norm.bias]
+        return p
+
+
+class PreActConvFunction(torch.autograd.Function):
+    """norm -> activate -> conv of ConvModule(activate_last=False) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, pu, x, *params):
+        u, norm, act = pu.conv, pu.norm, pu.act
+        xh = ops.to_nhwc_bf16(x, u.dtype)
+        stats = fold = None
+        if isinstance(norm, nn.GroupNorm):
+            h, stats = ops.gn_fwd(xh, norm.weight, norm.bias, norm.num_groups, norm.eps, None, act)
+            kind = 'gn'
+        elif norm is not None and norm.training:
+            if norm.momentum is None:
+                raise NotImplementedError('cumulative-average BatchNorm2d is not on the HIP path')
+            h, stats = ops.bn_train_fwd(xh, norm.weight, norm.bias, norm.running_mean, norm.running_var,
+                                        norm.momentum, norm.eps, None, act)
+            if norm.num_batches_tracked is not None:
+                norm.num_batches_tracked.add_(1)
+            kind = 'bnt'
+        elif norm is not None:
+            scale, shift, invstd = ops.bn_fold(norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps)
+            fold = (scale, invstd, norm.running_mean)
+            h = ops.channel_affine_fwd(xh, scale, shift, act)
+            kind = 'bn'
+        else:
+            h = ops.add_relu_mask(xh, None, xh) if act >= 1 else xh
+            kind = 'none'
+        if act == 2 and kind == 'none':
+            h = ops.clamp_max_(h, 6.0)       # exact: h holds 16-bit input values, min(x, 6) needs no rounding
+        y = unit_fwd(u, h)
+        ctx.pu, ctx.kind, ctx.xh, ctx.h, ctx.stats, ctx.fold = pu, kind, xh, h, stats, fold
+        return _as_nchw(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        pu, kind, xh, h = ctx.pu, ctx.kind, ctx.xh, ctx.h
+        u, norm, act = pu.conv, pu.norm, pu.act
+        g = ops.to_nhwc_bf16(dy, u.dtype)
+        grads = unit_wgrad(u, h, g)
+        norm_grads = []
+        dx = None
+        if ctx.needs_input_grad[1] or norm is not None:
+            gh = unit_dgrad(u, g, _hw(h))
+            if act >= 1:
+                gh = ops.act_mask(gh, h, 6.0 if act == 2 else float('inf'))
+            if kind == 'gn':
+                dx, dg, db = ops.gn_bwd(gh, xh, ctx.stats, norm.weight, norm.num_groups)
+                norm_grads = [dg, db]
+            elif kind == 'bnt':
+                dx, dg, db = ops.bn_train_bwd(gh, xh, ctx.stats, norm.weight)
+                norm_grads = [dg, db]
+            elif kind == 'bn':
+                scale, invstd, mean = ctx.fold
+                dx, dg, db = ops.channel_affine_bwd(gh, xh, scale, mean, invstd)
+                norm_grads = [dg, db]
+            else:
+                dx = gh
+        join_side_stream(g.device)
+        dx = _as_nchw(dx) if (dx is not None and ctx.needs_input_grad[1]) else None
+        return (None, dx) + tuple(grads) + tuple(norm_grads)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -60,9 +60,9 @@ class ConvModule(nn.Module):
     """conv (+bias) [+ BN] [+ ReLU] — the reference's ConvModule (layers.py:57-135).
 
     Same constructor, attributes (``conv``, ``norm``, ``activate``, ``with_norm`` ...) and state_dict keys.
-    Supported on the HIP path: ``activate_last=True`` with ``normalize`` in {None, BN in eval mode, GroupNorm
-    (``use_gn=True``)} and ``activation`` in {None, 'relu'} — the configurations FPN / PAFPN use.  'relu6' and the
-    pre-activation order raise ``NotImplementedError`` in ``forward``.
+    All five layer types of the reference's docstring are on the HIP path: conv, conv + BN/GN, conv + BN/GN + ReLU,
+    conv + ReLU, and (``activate_last=False``) BN/GN + ReLU + conv; ``activation`` 'relu' or 'relu6'; BatchNorm2d in
+    eval mode (folded) or training mode (batch statistics), GroupNorm via ``use_gn=True``.
     """
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
@@ -101,16 +101,21 @@ class ConvModule(nn.Module):
                 self.activate = nn.ReLU6(inplace=True)
 
     def hip_unit(self, dtype=torch.bfloat16):
-        """Prepared (cached) fused-conv unit of this module; raises for configurations not on the HIP path."""
-        if not self.activate_last:
-            raise NotImplementedError('ConvModule(activate_last=False) is not on the HIP path yet')
+        """Prepared (cached) fused unit of this module: a ``ConvUnit`` (conv -> [norm] -> [ReLU | ReLU6]) or, for
+        ``activate_last=False``, a ``PreActUnit`` ([norm] -> [ReLU | ReLU6] -> conv)."""
         if self.with_norm and not isinstance(self.norm, (nn.BatchNorm2d, nn.GroupNorm)):
             raise NotImplementedError('ConvModule norm %s is not on the HIP path' % type(self.norm).__name__)
-        if self.with_activation and self.activation != 'relu':
-            raise NotImplementedError("ConvModule activation %r is not on the HIP path yet" % self.activation)
-        return HF.prepare_unit(self, 'conv', self.conv, self.norm if self.with_norm else None,
+        if not self.activate_last:
+            conv = HF.prepare_unit(self, 'conv', self.conv, None, False, dtype)
+            act = 0 if not self.with_activation else (2 if self.activation == 'relu6' else 1)
+            return HF.PreActUnit(conv, self.norm if self.with_norm else None, act)
+        unit = HF.prepare_unit(self, 'conv', self.conv, self.norm if self.with_norm else None,
                                self.with_activation, dtype)
+        unit.act6 = self.with_activation and self.activation == 'relu6'
+        return unit
 
     def forward(self, x):
         unit = self.hip_unit(HF.pick_dtype(self, x))
+        if isinstance(unit, HF.PreActUnit):
+            return HF.PreActConvFunction.apply(unit, x, *unit.params())
         return HF.ConvUnitFunction.apply(unit, x, *unit.params())

@@ -53,6 +53,11 @@ def conv_out_size(h, k, stride, pad):
     return (h + 2 * pad - (d * (k - 1) + 1)) // stride + 1
 
 
+def _relu_code(relu):
+    """0 none / 1 ReLU / 2 ReLU6 from a bool or one of those codes (True is 1)."""
+    return 2 if (relu == 2 and relu is not True) else (1 if relu else 0)
+
+
 def make_epilogue(Cout, Ho, Wo, scale=None, shift=None, addend=None, addend_mode=ADD_NONE, relu=False,
                   mask_src=None, N=None, out_f32=False, dtype=None):
     _chk_vec(scale, "scale", Cout)
@@ -60,7 +65,7 @@ def make_epilogue(Cout, Ho, Wo, scale=None, shift=None, addend=None, addend_mode
     ep = Epilogue()
     ep.scale = scale.data_ptr() if scale is not None else None
     ep.shift = shift.data_ptr() if shift is not None else None
-    ep.relu = 1 if relu else 0
+    ep.relu = _relu_code(relu)
     ep.out_f32 = 1 if out_f32 else 0
     ep.addend_mode = ADD_NONE
     if addend is not None and addend_mode != ADD_NONE:
@@ -329,6 +334,62 @@ def add_relu_mask(a, b=None, mask_src=None):
     return out
 
 
+def clamp_max_(y, hi):
+    """In place y = min(y, hi): the upper clamp of nn.ReLU6 (layers.py:117-118) after a ReLU epilogue."""
+    _chk_act(y, "y")
+    _lib.check(_lib.load().tdn_clamp_max(_ptr(y), float(hi), y.numel(), dtype_code(y.dtype), _lib.stream_ptr()),
+               "tdn_clamp_max")
+    return y
+
+
+def act_mask(g, y, hi=float("inf")):
+    """g where 0 < y < hi else 0: backward of ReLU (hi = inf) / ReLU6 (hi = 6) from the activation's saved output."""
+    _chk_act(g, "g")
+    _chk_act(y, "y", None, g.dtype)
+    if y.shape != g.shape:
+        raise RuntimeError("act_mask: shape mismatch")
+    out = torch.empty_like(g)
+    _lib.check(_lib.load().tdn_act_mask(_ptr(g), _ptr(y), _ptr(out), float(hi), g.numel(), dtype_code(g.dtype),
+                                        _lib.stream_ptr()), "tdn_act_mask")
+    return out
+
+
+def channel_affine_fwd(x, scale, shift, act=0):
+    """act(x * scale[c] + shift[c]) on an NHWC activation: eval-mode BatchNorm2d (+ReLU / ReLU6) in front of a conv
+    (ConvModule(activate_last=False), layers.py:129-134).  act: 0 none, 1 ReLU, 2 ReLU6."""
+    _chk_act(x, "x")
+    C = x.shape[3]
+    _chk_vec(scale, "scale", C)
+    _chk_vec(shift, "shift", C)
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().tdn_channel_affine_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), x.numel() // C, C,
+                                                  int(act), dtype_code(x.dtype), _lib.stream_ptr()),
+               "tdn_channel_affine_fwd")
+    return y
+
+
+def channel_affine_bwd(g, x, scale, mean, invstd, dgamma=None, dbeta=None):
+    """(dx, dgamma, dbeta) of channel_affine_fwd from g = dL/dy already masked by the activation."""
+    _chk_act(g, "g")
+    _chk_act(x, "x", None, g.dtype)
+    C = x.shape[3]
+    for t, nm in ((scale, "scale"), (mean, "mean"), (invstd, "invstd")):
+        _chk_vec(t, nm, C)
+    lib = _lib.load()
+    npix = x.numel() // C
+    dx = torch.empty_like(x)
+    if dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    nbytes = lib.tdn_channel_affine_bwd_workspace(npix, C)
+    ws = _workspace(nbytes, x.device)
+    _lib.check(lib.tdn_channel_affine_bwd(_ptr(g), _ptr(x), _ptr(scale), _ptr(mean), _ptr(invstd), _ptr(dx),
+                                          _ptr(dgamma), _ptr(dbeta), 0.0, npix, C, _ptr(ws), ws.numel(),
+                                          dtype_code(x.dtype), _lib.stream_ptr()), "tdn_channel_affine_bwd")
+    return dx, dgamma, dbeta
+
+
 def to_nhwc_bf16(x, dtype=BF16):
     """Logical NCHW tensor -> NHWC `dtype` (N,H,W,C). Zero-copy when x already is a permuted NHWC tensor of that
     dtype.  (The name is historical: dtype may be torch.float16.)"""
@@ -509,7 +570,7 @@ def gn_fwd(z, gamma, beta, groups, eps=1e-5, addend=None, relu=False, addend_mod
     stats = torch.empty(N, C, 2, dtype=torch.float32, device=z.device)
     ws = _gn_ws(N, H, W, C, groups, z.device)
     _lib.check(_lib.load().tdn_gn_fwd(_ptr(z), _ptr(gamma), _ptr(beta), N, H, W, C, int(groups), float(eps),
-                                      _ptr(addend), int(addend_mode), 1 if relu else 0, _ptr(y), _ptr(stats), _ptr(ws),
+                                      _ptr(addend), int(addend_mode), _relu_code(relu), _ptr(y), _ptr(stats), _ptr(ws),
                                       ws.numel(),
                                       dtype_code(z.dtype), _lib.stream_ptr()), "tdn_gn_fwd")
     return y, stats
@@ -650,7 +711,7 @@ def bn_train_fwd(z, gamma, beta, running_mean=None, running_var=None, momentum=0
     ws = _gn_ws(N, H, W, C, C, z.device)
     _lib.check(_lib.load().tdn_bn_train_fwd(_ptr(z), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                             float(momentum), N, H, W, C, float(eps), _ptr(addend), int(addend_mode),
-                                            1 if relu else 0, _ptr(y), _ptr(stats), _ptr(ws), ws.numel(),
+                                            _relu_code(relu), _ptr(y), _ptr(stats), _ptr(ws), ws.numel(),
                                             dtype_code(z.dtype), _lib.stream_ptr()), "tdn_bn_train_fwd")
     return y, stats
 
