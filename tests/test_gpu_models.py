@@ -325,6 +325,21 @@ def test_resnext_vs_golden(T, manifest, golden_dir):
     assert w.grad.shape == w.shape and w.grad.stride() == w.stride()     # layout contract: no copy in AccumulateGrad
 
 
+def test_resnext_use_gn_keeps_training_mode_bn_in_downsample(T):
+    """Reference quirk (resnext.py:147,303-310): a use_gn=True ResNeXt has BatchNorm in its downsample branches and
+    leaves it in training mode — GroupNorm units and batch-statistics BN units in one net, forward and backward."""
+    m = T.ResNeXt(50, 4, 32, use_gn=True).cuda().train()
+    m.init_weights()
+    ds = [mod for name, mod in m.named_modules() if name.endswith("downsample.1")]
+    assert ds and all(isinstance(d, torch.nn.BatchNorm2d) and d.training for d in ds)
+    before = ds[0].running_mean.clone()
+    outs = m(det_tensor((2, 3, 64, 96), 13, -1, 1).cuda())
+    torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    assert not torch.equal(ds[0].running_mean, before) and int(ds[0].num_batches_tracked) == 1
+
+
 def test_graphed_step_matches_eager(T):
     """GraphedStep: one captured forward+backward replayed == the eager step, bit for bit (static tensors)."""
     m = T.ResNet(18).cuda().train()

@@ -8,8 +8,8 @@ divide 64 — true for the usual 32x4d / 32x8d / 64x4d settings.
 
 Reference quirk kept for state_dict / behaviour parity: ``_make_resX_layer`` builds the downsample norm WITHOUT
 ``use_gn`` (resnext.py:147), so a ``use_gn=True`` ResNeXt still has BatchNorm in its downsample branches — and leaves
-them in training mode (resnext.py:303-310 only switches BN to eval when ``use_gn`` is False).  Batch statistics are not
-on the HIP path: that combination raises ``NotImplementedError`` on ``forward`` (call ``.eval()`` on those layers).
+them in training mode (resnext.py:303-310 only switches BN to eval when ``use_gn`` is False).  Those branches then run
+with batch statistics (``tdn_bn_train_fwd/bwd``) like any training-mode BatchNorm2d on this path.
 """
 import math
 
