@@ -489,6 +489,10 @@ def main():
         ("pre_gn_relu6", 3, True, True, True, "relu6", False, False),
         ("pre_none_relu", 1, True, False, False, "relu", False, False),
         ("pre_bn_noact", 3, False, True, False, None, False, False),
+        # a conv with a bias AND a norm behind it: the reference warns (layers.py:84-85) and computes it
+        ("post_bn_bias_relu", 3, True, True, False, "relu", True, False),
+        ("post_gn_bias", 1, True, True, True, None, True, False),
+        ("post_bn_bias_train_relu6", 3, True, True, False, "relu6", True, True),
     ]
     man["conv_module"] = {"input": {"shape": [2, 64, 12, 16], "lo": -8.0, "hi": 8.0}, "cases": []}
     for ci, (tag, k, bias, norm, use_gn, actv, last, training) in enumerate(cm_cases):

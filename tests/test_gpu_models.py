@@ -428,6 +428,13 @@ def test_conv_module_relu6_and_preactivation_vs_golden(T, manifest, golden_dir):
                 "dx": rel_l2(_f32(x.grad), torch.from_numpy(gold[tag + "/dx"]))}
         for k_, p in m.named_parameters():
             errs[k_] = rel_l2(p.grad.float().cpu(), torch.from_numpy(gold[tag + "/grad/" + k_]))
+        if c["training"] and c["bias"] and c["activate_last"] and c["normalize"] and not c["use_gn"]:
+            # batch statistics cancel a bias in front of them: its gradient is zero up to round-off on both sides
+            # (the reference's is ~1e-7 noise), so compare magnitudes against the norm's own bias gradient instead
+            scale = float(m.norm.bias.grad.abs().max())
+            assert float(m.conv.bias.grad.abs().max()) <= 1e-3 * scale
+            assert float(np.abs(gold[tag + "/grad/conv.bias"]).max()) <= 1e-3 * scale
+            errs.pop("conv.bias")
         _record("conv_module_" + tag, [errs[k_] for k_ in sorted(errs)])
         # bf16 activations (2^-9 per stored value: measured <= 2.4e-3).  The kernels keep values under 6 under 6 when
         # they store them (relu6_top), so the backward's mask 0 < y < 6 agrees with the fp32 reference element for

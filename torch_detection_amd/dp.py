@@ -130,6 +130,8 @@ def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True, dty
         units += order
     numels, owners = [], []
     for u in units:
+        if u.bias_and_norm:
+            raise NotImplementedError('gradient sinks for a conv with both a bias and a norm are not implemented')
         for p in u.params():
             numels.append(p.numel())
             owners.append((u, p))

@@ -79,9 +79,9 @@ class ConvUnit(object):
         # BatchNorm2d in training mode (batch statistics; ResNet(bn_eval=False), resnet.py:270-276) cannot be folded
         # either: decided at refresh() time from ``bn.training`` and run like GroupNorm (conv raw -> tdn_bn_train_fwd)
         self.bnt = False
-        if bn is not None and conv.bias is not None:
-            raise NotImplementedError('a conv with both a bias and a norm layer is not on the HIP path (the reference '
-                                      'builds its normalised convs without bias: layers.py:12-47, fpn.py:26)')
+        # a conv with BOTH a bias and a norm behind it (ConvModule warns about it, layers.py:84-85, and computes it):
+        # eval-mode BN folds the bias into the shift; GroupNorm / training-mode BN get it in the raw conv's epilogue
+        self.bias_and_norm = bn is not None and conv.bias is not None
         if self.gn:
             C, G = bn.num_channels, bn.num_groups
             if C != self.Cout or C & (C - 1) or not 64 <= C <= 2048 or not bn.affine:
@@ -94,10 +94,10 @@ class ConvUnit(object):
 
     def params(self):
         p = [self.conv.weight]
+        if self.conv.bias is not None:
+            p.append(self.conv.bias)
         if self.bn is not None:
             p += [self.bn.weight, self.bn.bias]
-        elif self.conv.bias is not None:
-            p.append(self.conv.bias)
         return p
 
     def _version_key(self):
@@ -106,6 +106,8 @@ class ConvUnit(object):
         if self.bn is not None and not self.gn and not self.bn.training:
             for t in (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var):
                 key += [t.data_ptr(), t._version]
+            if self.conv.bias is not None:
+                key += [self.conv.bias.data_ptr(), self.conv.bias._version]
         elif self.conv.bias is not None:
             key += [self.conv.bias.data_ptr()]
         return tuple(key)
@@ -127,11 +129,16 @@ class ConvUnit(object):
             if w.dtype != torch.float32:
                 raise NotImplementedError('parameters must be float32 (bf16 operands are derived on the fly)')
             if self.gn or self.bnt:
-                self.scale = self.shift = self.invstd = self.mean = None   # gamma / beta are read at launch time
+                self.scale = self.invstd = self.mean = None   # gamma / beta are read at launch time
+                self.shift = self.conv.bias.detach() if self.conv.bias is not None else None   # z = conv + bias
             elif self.bn is not None:
                 self.scale, self.shift, self.invstd = ops.bn_fold(self.bn.weight, self.bn.bias, self.bn.running_mean,
                                                                   self.bn.running_var, self.bn.eps)
                 self.mean = self.bn.running_mean
+                if self.conv.bias is not None:
+                    # bn(conv + b) = scale * conv + (shift + scale * b);  z - mean = conv - (mean - b)
+                    self.shift = self.shift + self.scale * self.conv.bias.detach()
+                    self.mean = self.bn.running_mean - self.conv.bias.detach()
             else:
                 self.scale = self.invstd = self.mean = None
                 self.shift = self.conv.bias.detach() if self.conv.bias is not None else None
@@ -232,9 +239,9 @@ def unit_fwd(u, x, addend=None, addend_mode=ADD_NONE, relu=None):
                                    relu)
         return ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode, relu)
     if u.groups > 1:
-        z = ops.gconv2d_fwd(x, u.w_fwd, u.groups, u.k, u.stride, u.pad)
+        z = ops.gconv2d_fwd(x, u.w_fwd, u.groups, u.k, u.stride, u.pad, None, u.shift)
     else:
-        z = ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad)
+        z = ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad, None, u.shift)
     if addend is None:
         addend_mode = ADD_SAME
     y, stats = _dyn_norm_fwd(u, z, addend, relu, addend_mode)
@@ -460,6 +467,10 @@ def unit_wgrad(u, x_in, g, img_hw=None):
         u.on_grads(u, side)
     if sink is not None:
         return [None] * len(u.params())
+    if u.bias_and_norm:
+        # dyn: db = sum of dL/dz = the bias gradient.  Folded eval-mode BN: dL/dz = g * scale, so the bias gradient is
+        # scale * dbeta — left as None here and filled in by the caller once the side stream has been joined
+        return [dw_view, db, gn_affine[0], gn_affine[1]] if dyn else [dw_view, None, dg, db]
     if dyn:
         return [dw_view, gn_affine[0], gn_affine[1]]
     if u.bn is not None:
@@ -502,6 +513,8 @@ class ConvUnitFunction(torch.autograd.Function):
         grads = unit_wgrad(u, ctx.xh, g)
         dx = _as_nchw(unit_dgrad(u, g, _hw(ctx.xh))) if ctx.needs_input_grad[1] else None
         join_side_stream(g.device)
+        if u.bias_and_norm and grads[1] is None and u.sink is None:
+            grads[1] = u.scale * grads[3]          # eval-mode BN behind a biased conv (see unit_wgrad)
         return (None, dx) + tuple(grads)
 
 
