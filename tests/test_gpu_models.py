@@ -405,7 +405,8 @@ def test_branch_streams_change_nothing(T, depth, monkeypatch):
         assert all(torch.equal(a, b) for a, b in zip(g, ref_g))
 
 
-def test_conv_module_relu6_and_preactivation_vs_golden(T, manifest, golden_dir):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_conv_module_relu6_and_preactivation_vs_golden(T, manifest, golden_dir, dtype):
     """ConvModule on the HIP path with activation='relu6' and with activate_last=False (norm -> activation -> conv;
     BatchNorm2d in eval and in training mode, GroupNorm, no norm) against the reference golden: output, input
     gradient, every parameter gradient, running statistics."""
@@ -422,7 +423,9 @@ def test_conv_module_relu6_and_preactivation_vs_golden(T, manifest, golden_dir):
         m.load_state_dict(fill_state_dict(m.state_dict(), c["state_seed"]))
         m.cuda().train(c["training"])
         x = det_tensor(tuple(i["shape"]), c["input_seed"], i["lo"], i["hi"]).cuda().requires_grad_(True)
+        m.compute_dtype = dtype
         y = m(x)
+        assert y.dtype == dtype
         y.backward(det_tensor(tuple(y.shape), c["cot_seed"], -1, 1).cuda().to(y.dtype))
         errs = {"y": rel_l2(_f32(y), torch.from_numpy(gold[tag + "/y"])),
                 "dx": rel_l2(_f32(x.grad), torch.from_numpy(gold[tag + "/dx"]))}
@@ -435,7 +438,7 @@ def test_conv_module_relu6_and_preactivation_vs_golden(T, manifest, golden_dir):
             assert float(m.conv.bias.grad.abs().max()) <= 1e-3 * scale
             assert float(np.abs(gold[tag + "/grad/conv.bias"]).max()) <= 1e-3 * scale
             errs.pop("conv.bias")
-        _record("conv_module_" + tag, [errs[k_] for k_ in sorted(errs)])
+        _record("conv_module_%s_%s" % (tag, "f16" if dtype == torch.float16 else "bf16"), [errs[k_] for k_ in sorted(errs)])
         # bf16 activations (2^-9 per stored value: measured <= 2.4e-3).  The kernels keep values under 6 under 6 when
         # they store them (relu6_top), so the backward's mask 0 < y < 6 agrees with the fp32 reference element for
         # element; rounding (5.984, 6) up to 6.0 instead cost 4e-2 on these gradients.
