@@ -123,6 +123,41 @@ int tdn_conv2d_wgrad(const void* x, const void* g, const void* w_fwd, const floa
                      int stride, int pad, void* workspace, int64_t workspace_bytes, int dtype,
                      void* stream);
 
+/* Grouped launch: the weight / affine gradients of SEVERAL convs (e.g. every conv of one ResNet stage, or of the
+ * FPN) in as few launches as the tile shapes allow — autograd of the nn.Conv2d / BatchNorm2d parameters created at
+ * models/backbone/resnet.py:74-91,214-216 and models/necks/fpn.py:44-58, which the reference leaves to one autograd
+ * node per layer.  Members are independent; each is described like one tdn_conv2d_wgrad / tdn_stem_conv_wgrad /
+ * tdn_gconv2d_wgrad call.  The library cuts every member's pixel range (the GEMM's reduction index) into splits
+ * sized so that the GROUP fills the chip — a member that can be reduced by one workgroup per tile writes its
+ * gradient directly (no fp32 partial slabs) — and reduces the rest, plus every member's BN / bias gradients, in ONE
+ * finalize launch, in a fixed order (bit-reproducible run to run).  items / n: HOST array. */
+enum { TDN_WGRAD_CONV = 0, TDN_WGRAD_STEM = 1, TDN_WGRAD_GCONV = 2 };
+typedef struct tdn_wgrad_item {
+  const void* x;       /* conv input, NHWC 16-bit [N][H][W][Cin]; TDN_WGRAD_STEM: the staged image xp (tdn_stage_image) */
+  const void* g;       /* dL/d(pre-activation output), NHWC 16-bit [N][Ho][Wo][Cout] */
+  const void* w_fwd;   /* packed forward weights (tdn_pack_conv_weight / _stem_ / _gconv_); read for dgamma */
+  const float* scale;  /* BN scale or NULL (= 1) */
+  const float* mean;   /* BN mean, or NULL: bias mode */
+  const float* invstd; /* BN 1/sqrt(var + eps), or NULL */
+  float* dw;           /* as in the single-layer call of the member's kind */
+  float* dgamma;       /* may be NULL in bias mode */
+  float* dbeta;        /* may be NULL */
+  float beta;          /* 0: overwrite, else accumulate beta * old + new */
+  int32_t kind;        /* TDN_WGRAD_* */
+  int32_t N, H, W;     /* input size (STEM: the image size, even) */
+  int32_t Cin, Cout;   /* GCONV: Cin = Cout = C */
+  int32_t k, stride, pad;   /* ignored for STEM */
+  int32_t groups;      /* GCONV only */
+  int32_t reserved;
+} tdn_wgrad_item;
+int64_t tdn_wgrad_group_workspace(const tdn_wgrad_item* items, int n, int dtype);
+int tdn_wgrad_group(const tdn_wgrad_item* items, int n, void* workspace, int64_t workspace_bytes, int dtype,
+                    void* stream);
+/* Host-only: the decomposition tdn_wgrad_group would use.  per_item[n][8] = {kernel (0 tap-per-tile, 1 nine-tap),
+ * tile_co, tile_ci, splits, pixels per split, direct (1: no slabs), workgroups, fp32 slab bytes / 1024};
+ * totals[4] = {gradient-kernel launches, finalize launches, workgroups, slab KiB}. */
+int tdn_wgrad_group_plan(const tdn_wgrad_item* items, int n, int dtype, int32_t* per_item, int32_t* totals);
+
 /* ---- grouped convolution (ResNeXt) -----------------------------------
  * conv3x3_group(..., groups=cardinality) of models/backbone/resnext.py:26-28,82-83: C channels in and out,
  * `groups` groups.  Computed in block-diagonal form: every 64-channel block of the output multiplies only the same

@@ -40,6 +40,23 @@ class Epilogue(ctypes.Structure):
 
 _EP = ctypes.POINTER(Epilogue)
 
+
+class WgradItem(ctypes.Structure):
+    """Mirror of ``tdn_wgrad_item`` (include/tdn.h): one member of a grouped weight-gradient launch."""
+    _fields_ = [
+        ("x", c_void_p), ("g", c_void_p), ("w_fwd", c_void_p),
+        ("scale", c_void_p), ("mean", c_void_p), ("invstd", c_void_p),
+        ("dw", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
+        ("beta", c_float), ("kind", ctypes.c_int32),
+        ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32),
+        ("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
+        ("groups", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
+_WI = ctypes.POINTER(WgradItem)
+
 # name -> (restype, argtypes); must list every symbol of include/tdn.h (tests/test_abi.py checks this)
 SIGNATURES = {
     "tdn_last_error": (ctypes.c_char_p, []),
@@ -52,6 +69,10 @@ SIGNATURES = {
     "tdn_conv2d_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
     "tdn_conv2d_wgrad_workspace": (c_i64, [c_int] * 8),
     "tdn_conv2d_wgrad": (c_int, [c_void_p] * 9 + [c_float] + [c_int] * 8 + [c_void_p, c_i64, c_int, c_void_p]),
+    "tdn_wgrad_group_workspace": (c_i64, [_WI, c_int, c_int]),
+    "tdn_wgrad_group": (c_int, [_WI, c_int, c_void_p, c_i64, c_int, c_void_p]),
+    "tdn_wgrad_group_plan": (c_int, [_WI, c_int, c_int, ctypes.POINTER(ctypes.c_int32),
+                                     ctypes.POINTER(ctypes.c_int32)]),
     "tdn_stage_image": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_int,
                                 c_void_p]),
     "tdn_stem_conv_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [_EP, c_int, c_void_p]),

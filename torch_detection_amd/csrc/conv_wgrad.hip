@@ -1,4 +1,4 @@
-// Weight-gradient GEMM on MFMA (gfx950) + finalize (BN-affine / bias grads, split-K reduction).
+// Weight-gradient GEMMs on MFMA (gfx950), launched per GROUP of layers, + one grouped finalize pass.
 //
 // Autograd of nn.Conv2d weights / BatchNorm2d affine / conv bias for the layers built at
 // models/backbone/resnet.py:74-91,214-216 and models/necks/fpn.py:44-58 (the reference never calls
@@ -9,24 +9,84 @@
 // fragments are fetched with ds_read_b64_tr_b16 (hardware transpose read) from row-major LDS tiles that
 // are filled by 16-byte LDS-DMA.  D is kept as D[ci][co] so a lane owns 4 consecutive ci (float4 stores).
 // sum_m g[m][co] (dbeta / dbias) comes from one extra MFMA against a ones fragment — no extra traffic.
-// Split-K over pixels writes fp32 slabs; tdn finalize reduces them in a fixed order (deterministic).
+//
+// Grouping.  The weight gradients of one layer are a small GEMM output (64x64 ... 2048x512) under a very long
+// reduction (2,100 ... 268,800 pixels): alone, a layer can only fill 256 CUs by cutting the pixel range into many
+// splits, each of which writes a full fp32 copy of its tile that a second kernel has to read back.  A GROUP of layers
+// (a ResNet stage, the FPN) fills the chip together, so the splits are sized for the group (tdn_wgrad_group): the
+// work list of one launch spans all members (descriptors travel in the kernel-argument block), members whose
+// reduction fits one workgroup per tile write their gradient directly, and the remaining slabs, the BN gamma / beta
+// and bias gradients of EVERY member are reduced by one finalize launch, in a fixed order (deterministic).
 #include "common.h"
+#include <limits.h>
+#include <string.h>
 #include <type_traits>
+#include <algorithm>
+#include <math.h>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 
-struct WgradParams {
+constexpr int WG_MAXI = 26;    // members per gradient launch: the kernel-argument block must stay under 4 KB
+constexpr int FIN_MAXI = 30;   // members per finalize launch
+
+// One member of a grouped launch, as the kernels see it.
+struct WgItem {
   const bf16_t* x;
   const bf16_t* g;
-  float* slab;      // [splitk][Cout][Ktot]
-  float* colsum;    // [splitk][Cout]
+  const bf16_t* w_fwd;   // direct members with BN: read for the partial sum_k w * G
+  const float* scale;    // direct members: BN scale folded into the stored gradient (NULL = 1)
+  float* out;            // slab [splitk][Cout][Ktot]; direct members: dw itself ([Cout][Ktot])
+  float* colsum;         // [splitk][Cout]
+  float* dotpart;        // direct members with BN: [tiles_k][Cout] partial sum_k w * G per K tile, else NULL
   int Hin, Win, Cpix, Ktap;   // x geometry (pixel stride Cpix elements, Ktap elements consumed per tap)
   int Ho, Wo, Cout, sa;
   int M, Mchunk, splitk;
   int ntaps, Ktot;
-  int tiles_co, tiles_k;     // tiles over Cout, tiles over (tap, ci)
-  int taps[9];               // (dh+64) | (dw+64)<<8
-  int grouped;               // block-diagonal grouped conv: the ci block of a tile is its co block (64 x 64 tiles)
+  int tiles_co, tiles_k;      // tiles over Cout, tiles over (tap, ci)
+  int tapgen;                 // k | pad << 8 | dilation << 16 | stem << 24: tap t -> (dh, dw)
+  int grouped;                // block-diagonal grouped conv: the ci block of a tile is its co block (64 x 64 tiles)
+  int direct;
+  float beta;
+  int reserved;
 };
 
+struct WgGroup {
+  int nitems, reserved;
+  int blk_start[WG_MAXI + 2];   // first workgroup of member i (a multiple of 8); INT_MAX past the last member
+  WgItem it[WG_MAXI];
+};
+static_assert(sizeof(WgGroup) <= 4096, "kernel-argument block too large");
+
+// tap t of a member -> displacement of the input pixel: (kh * dil - pad, kw * dil - pad); stem: one "tap" per kernel
+// row (8 pixels x 4 channels contiguous)
+__device__ __forceinline__ void wg_tap(int tapgen, int t, int& dh, int& dw) {
+  const int k = tapgen & 0xff, pad = (tapgen >> 8) & 0xff, dil = (tapgen >> 16) & 0xff;
+  if (tapgen >> 24) { dh = t; dw = 0; return; }
+  const int kh = t / k, kw = t - kh * k;
+  dh = kh * dil - pad;
+  dw = kw * dil - pad;
+}
+
+// XCD-aware work map inside a member: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch; speed only; the
+// member's first workgroup is a multiple of 8).  XCD x owns the pixel splits s = x (mod 8) and walks all tiles of one
+// split before the next, so the ~ntiles workgroups that stream the same g / x pixel range run together on ONE L2
+// instead of being dealt over all eight.
+__device__ __forceinline__ bool wg_work(int bid, int splitk, int ntiles, int& split, int& tile) {
+  if (splitk >= 8) {
+    const int xj = bid >> 3;
+    split = (bid & 7) + 8 * (xj / ntiles);
+    tile = xj - (xj / ntiles) * ntiles;
+  } else {   // too few splits to feed 8 XCDs that way: plain order, tile fastest
+    split = bid / ntiles;
+    tile = bid - split * ntiles;
+  }
+  return split < splitk;
+}
+static int wg_blocks(int splitk, int ntiles) {
+  const int slots = splitk >= 8 ? 8 * ((splitk + 7) / 8) : splitk;
+  return (slots * ntiles + 7) & ~7;
+}
 
 // 32-byte-chunk XOR swizzle for tr-read tiles, by row bytes.
 template <int RB>
@@ -36,50 +96,59 @@ __device__ __forceinline__ int tr_swz(int row) {
   else return (row >> 3) & 1;
 }
 
-template <int BMW /*co*/, int BNW /*ci*/, int WM = 2, int WN = 2, bool F16 = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradParams p) {
+template <int N>
+__device__ __forceinline__ void wg_wait_vm_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// One tap per tile: a workgroup owns BMW (co) x BNW (ci of one tap) of one member for one pixel split.
+// NST-deep LDS ring filled by LDS-DMA: while K-step t is multiplied the loads of steps t+1 .. t+NST-2 stay in
+// flight (counted vmcnt, one s_barrier per K-step).
+// ---------------------------------------------------------------------------------------------
+template <int BMW /*co*/, int BNW /*ci*/, int WM, int WN, int NST, bool F16>
+__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_group_kernel(const WgGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BKW = 64;                       // pixels per stage
   constexpr int RBG = BMW * 2, RBX = BNW * 2;   // row bytes
   constexpr int G_BYTES = BKW * RBG, X_BYTES = BKW * RBX, STAGE = G_BYTES + X_BYTES;
   constexpr int RPIG = 1024 / RBG, RPIX = 1024 / RBX;   // rows per wave-instruction
   constexpr int NW = WM * WN;
-  constexpr int G_IT = BKW / (RPIG * NW) > 0 ? BKW / (RPIG * NW) : 1;
-  constexpr int X_IT = BKW / (RPIX * NW) > 0 ? BKW / (RPIX * NW) : 1;
-  constexpr bool G_PART = (RPIG * NW > BKW), X_PART = (RPIX * NW > BKW);  // fewer than NW waves needed
+  constexpr int G_IT = BKW / (RPIG * NW), X_IT = BKW / (RPIX * NW);
+  static_assert(G_IT >= 1 && X_IT >= 1, "every wave must issue the same number of loads per stage (counted vmcnt)");
+  constexpr int LOADS = G_IT + X_IT;
+  static_assert(LOADS * (NST - 2) < 64, "vmcnt immediate out of range");
   constexpr int WTM = BMW / WM, WTN = BNW / WN, FM = WTM / 16, FN = WTN / 16;  // per-wave co / ci frags
   static_assert(FM >= 1 && FN >= 1, "tile too small");
   // the per-lane swizzle constants assume the row offset between a lane's loads keeps row bits 0..3
   static_assert((RPIG * NW) % 16 == 0 && (RPIX * NW) % 16 == 0, "loader round must be a multiple of 16 rows");
+  static_assert(WN * BMW * 4 <= NST * STAGE, "cross-wave reduction buffer must fit the ring");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // XCD-aware work map: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch; speed only).  XCD x owns
-  // the pixel splits s = x (mod 8) and walks all tiles of one split before the next, so the ~ntiles workgroups
-  // that stream the same g / x pixel range run together on ONE L2 instead of being dealt over all eight.
+  // ---- which member, which (split, tile) ----
+  int idx = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXI; ++i) idx += ((int)blockIdx.x >= grp.blk_start[i]) ? 1 : 0;
+  const WgItem& p = grp.it[idx];
   const int ntiles = p.tiles_co * p.tiles_k;
   int split, tile;
-  if (p.splitk >= 8) {
-    const int xj = blockIdx.x >> 3;
-    split = (blockIdx.x & 7) + 8 * (xj / ntiles);
-    tile = xj - (xj / ntiles) * ntiles;
-  } else {   // too few splits to feed 8 XCDs that way: plain order, tile fastest
-    split = blockIdx.x / ntiles;
-    tile = blockIdx.x - split * ntiles;
-  }
-  if (split >= p.splitk) return;
+  if (!wg_work((int)blockIdx.x - grp.blk_start[idx], p.splitk, ntiles, split, tile)) return;
   const int tile_co = tile % p.tiles_co, tile_k = tile / p.tiles_co;
   const int co0 = tile_co * BMW;
   const int kt_per_tap = p.Ktap / BNW;
   const int tap_i = tile_k / kt_per_tap;
   const int ci_k = (tile_k - tap_i * kt_per_tap) * BNW;   // column offset inside the tap's K range (slab index)
   const int ci0 = p.grouped ? co0 : ci_k;                 // channel offset in x
-  const int tp = p.taps[tap_i];
-  const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64;
+  int dh, dw;
+  wg_tap(p.tapgen, tap_i, dh, dw);
   const int m_begin = split * p.Mchunk;
   const int m_end = min(p.M, m_begin + p.Mchunk);
+  const int Cout = p.Cout, Cpix = p.Cpix, Hin = p.Hin, Win = p.Win, sa = p.sa, Wo = p.Wo, Ho = p.Ho;
+  const bf16_t* const gx = p.x;
+  const bf16_t* const gg = p.g;
 
   // ---- loader constants ----
   constexpr int CPRG = RBG / 16, CPRX = RBX / 16;  // 16B chunks per row
@@ -93,51 +162,49 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
 
   // pixel decode state for this thread's x rows (advanced incrementally by BKW per stage)
   int xa[X_IT], xb[X_IT], ximg[X_IT];
-  const int HoWo = p.Ho * p.Wo;
+  const int HoWo = Ho * Wo;
 #pragma unroll
   for (int it = 0; it < X_IT; ++it) {
     const int m = m_begin + it * (RPIX * NW) + x_row0;
     const int img = m / HoWo;
     const int rem = m - img * HoWo;
     ximg[it] = img;
-    xa[it] = rem / p.Wo;
-    xb[it] = rem - xa[it] * p.Wo;
+    xa[it] = rem / Wo;
+    xb[it] = rem - xa[it] * Wo;
   }
 
+  // LDS-DMA of the 64 pixels from mt into ring slot s; past the end of the split: the zero page (keeps the vmcnt
+  // bookkeeping uniform)
   auto stage_load = [&](int mt, int s) {
     char* sG = smem + s * STAGE;
     char* sX = sG + G_BYTES;
-    if (!G_PART || g_row0 < BKW) {
 #pragma unroll
-      for (int it = 0; it < G_IT; ++it) {
-        const int r = it * (RPIG * NW) + g_row0;
-        const int m = mt + r;
-        const bf16_t* src = (m < m_end) ? p.g + ((int64_t)m * p.Cout + co0 + g_src_el) : zero + (g_src_el & 127);
-        glds16_async(src, sG + (it * (RPIG * NW) + wave * RPIG) * RBG);
-      }
+    for (int it = 0; it < G_IT; ++it) {
+      const int r = it * (RPIG * NW) + g_row0;
+      const int m = mt + r;
+      const bf16_t* src = (m < m_end) ? gg + ((int64_t)m * Cout + co0 + g_src_el) : zero + (g_src_el & 127);
+      glds16_async(src, sG + (it * (RPIG * NW) + wave * RPIG) * RBG);
     }
-    if (!X_PART || x_row0 < BKW) {
 #pragma unroll
-      for (int it = 0; it < X_IT; ++it) {
-        const int r = it * (RPIX * NW) + x_row0;
-        const int m = mt + r;
-        const int h = xa[it] * p.sa + dh, w = xb[it] * p.sa + dw;
-        const bool ok = (m < m_end) && ((unsigned)h < (unsigned)p.Hin) && ((unsigned)w < (unsigned)p.Win);
-        const bf16_t* src = ok ? p.x + (((int64_t)(ximg[it] * p.Hin + h) * p.Win + w) * p.Cpix + ci0 + x_src_el)
-                               : zero + (x_src_el & 127);
-        glds16_async(src, sX + (it * (RPIX * NW) + wave * RPIX) * RBX);
-        // advance to the next stage's pixel
-        xb[it] += BKW;
-        while (xb[it] >= p.Wo) { xb[it] -= p.Wo; xa[it] += 1; }
-        while (xa[it] >= p.Ho) { xa[it] -= p.Ho; ximg[it] += 1; }
-      }
+    for (int it = 0; it < X_IT; ++it) {
+      const int r = it * (RPIX * NW) + x_row0;
+      const int m = mt + r;
+      const int h = xa[it] * sa + dh, w = xb[it] * sa + dw;
+      const bool ok = (m < m_end) && ((unsigned)h < (unsigned)Hin) && ((unsigned)w < (unsigned)Win);
+      const bf16_t* src = ok ? gx + (((int64_t)(ximg[it] * Hin + h) * Win + w) * Cpix + ci0 + x_src_el)
+                             : zero + (x_src_el & 127);
+      glds16_async(src, sX + (it * (RPIX * NW) + wave * RPIX) * RBX);
+      // advance to the next stage's pixel
+      xb[it] += BKW;
+      while (xb[it] >= Wo) { xb[it] -= Wo; xa[it] += 1; }
+      while (xa[it] >= Ho) { xa[it] -= Ho; ximg[it] += 1; }
     }
   };
 
   // ---- fragment reader constants (ds_read_b64_tr_b16) ----
   const int wm = wave / WN, wn = wave % WN;
-  const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const int rrow = 8 * grp + q;                 // + kk*32 + 4*half
+  const int grp4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int rrow = 8 * grp4 + q;                 // + kk*32 + 4*half
   const int fG = tr_swz<RBG>(rrow), fX = tr_swz<RBX>(rrow);
   int g_off[FM], x_off[FN];
 #pragma unroll
@@ -166,12 +233,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
 
   const int T = (m_end > m_begin) ? ceil_div(m_end - m_begin, BKW) : 0;
   if (T > 0) {
-    stage_load(m_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) stage_load(m_begin + s * BKW, s);
+    int slot = 0, fill = NST - 1;
     for (int t = 0; t < T; ++t) {
-      if (t + 1 < T) stage_load(m_begin + (t + 1) * BKW, (t + 1) & 1);
-      const char* sG = smem + (t & 1) * STAGE;
+      wg_wait_vm_and_barrier<LOADS * (NST - 2)>();   // K-step t has landed for every wave; slot (t-1) is free
+      stage_load(m_begin + (t + NST - 1) * BKW, fill);
+      const char* sG = smem + slot * STAGE;
       const char* sX = sG + G_BYTES;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -202,23 +270,71 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
             acc1[i] = mfma16<F16>(ones, gf[i], acc1[i]);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      slot = (slot + 1 == NST) ? 0 : slot + 1;
+      fill = (fill + 1 == NST) ? 0 : fill + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail loads still target the ring
   }
 
-  // ---- store: lane holds ci = ci_base + 4*grp .. +3 for co = co_base + (lane&15) ----
+  // ---- store: lane holds ci = ci_base + 4*grp4 .. +3 for co = co_base + (lane&15) ----
   const int fr = lane & 15;
-  float* slab = p.slab + (int64_t)split * p.Cout * p.Ktot;
+  const int Ktot = p.Ktot;
+  if (!p.direct) {
+    float* slab = p.out + (int64_t)split * Cout * Ktot;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int co = co0 + wm * WTM + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int kidx = tap_i * p.Ktap + ci_k + wn * WTN + j * 16 + grp4 * 4;
+        *(f32x4_t*)(slab + (int64_t)co * Ktot + kidx) = acc[i][j];
+      }
+      if (do_colsum && grp4 == 0) p.colsum[(int64_t)split * Cout + co] = acc1[i][0];
+    }
+    return;
+  }
+  // ---- direct member (one split): the gradient itself, BN scale folded, + this tile's share of sum_k w * G ----
+  const float beta = p.beta;
+  const bool want_dot = p.dotpart != nullptr;
+  float dpart[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int co = co0 + wm * WTM + i * 16 + fr;
+    const float sc = p.scale ? p.scale[co] : 1.f;
+    float d = 0.f;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      const int kidx = tap_i * p.Ktap + ci_k + wn * WTN + j * 16 + grp * 4;
-      *(f32x4_t*)(slab + (int64_t)co * p.Ktot + kidx) = acc[i][j];
+      const int kidx = tap_i * p.Ktap + ci_k + wn * WTN + j * 16 + grp4 * 4;
+      const f32x4_t a = acc[i][j];
+      if (want_dot) {
+        const f32x4_t wv = load4_f32<F16>(p.w_fwd + (int64_t)co * Ktot + kidx);
+        d += ((wv[0] * a[0] + wv[1] * a[1]) + wv[2] * a[2]) + wv[3] * a[3];
+      }
+      f32x4_t* o = (f32x4_t*)(p.out + (int64_t)co * Ktot + kidx);
+      f32x4_t v = a * sc;
+      if (beta != 0.f) v += *o * beta;
+      *o = v;
     }
-    if (do_colsum && grp == 0) p.colsum[(int64_t)split * p.Cout + co] = acc1[i][0];
+    dpart[i] = d;
+    if (do_colsum && grp4 == 0) p.colsum[co] = acc1[i][0];
+  }
+  if (want_dot) {
+    float* red = (float*)smem;
+    __syncthreads();   // every wave is done reading the ring
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float d = dpart[i];
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      if (grp4 == 0) red[wn * BMW + wm * WTM + i * 16 + fr] = d;
+    }
+    __syncthreads();
+    for (int c = tid; c < BMW; c += NW * 64) {
+      float s = red[c];
+#pragma unroll
+      for (int w = 1; w < WN; ++w) s += red[w * BMW + c];
+      p.dotpart[(int64_t)tile_k * Cout + co0 + c] = s;
+    }
   }
 }
 
@@ -236,10 +352,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradPar
 //     read from the zero page; tap (dh, dw) reads its fragments from window dh at a row offset of 1 + dw.
 // 43 KB of LDS-DMA per K-step (two stages: 86 KB of LDS, one workgroup per CU) feed 9 x 128 x 64 x 64 MACs: 219 flop/B
 // against 51 for the 256x64 single-tap tile.
-// Needs W >= 8 (at most one line end per 8 consecutive pixels).  Slab layout and finalize pass are unchanged:
-// slab[split][co][tap*Cin + ci].
+// Needs W >= 8 (at most one line end per 8 consecutive pixels).  Slab layout: slab[split][co][tap*Cin + ci].
 template <bool F16>
-__global__ __launch_bounds__(512) void conv_wgrad9_kernel(const WgradParams p) {
+__global__ __launch_bounds__(512) void conv_wgrad9_group_kernel(const WgGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BKW = 64, BMW = 128, BNW = 64;
   constexpr int RBG = BMW * 2, RBX = BNW * 2;                 // 256 / 128 bytes per row
@@ -255,22 +370,22 @@ __global__ __launch_bounds__(512) void conv_wgrad9_kernel(const WgradParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+  int idx = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXI; ++i) idx += ((int)blockIdx.x >= grp.blk_start[i]) ? 1 : 0;
+  const WgItem& p = grp.it[idx];
   const int ntiles = p.tiles_co * p.tiles_k;
   int split, tile;
-  if (p.splitk >= 8) {
-    const int xj = blockIdx.x >> 3;
-    split = (blockIdx.x & 7) + 8 * (xj / ntiles);
-    tile = xj - (xj / ntiles) * ntiles;
-  } else {
-    split = blockIdx.x / ntiles;
-    tile = blockIdx.x - split * ntiles;
-  }
-  if (split >= p.splitk) return;
+  if (!wg_work((int)blockIdx.x - grp.blk_start[idx], p.splitk, ntiles, split, tile)) return;
   const int tile_co = tile % p.tiles_co, tile_ci = tile / p.tiles_co;
   const int co0 = tile_co * BMW, ci0 = tile_ci * BNW;
   const int m_begin = split * p.Mchunk;
-  const int m_end = min(p.M, m_begin + p.Mchunk);
+  const int pM = p.M;
+  const int m_end = min(pM, m_begin + p.Mchunk);
   const int W = p.Wo, H = p.Ho;            // stride 1, pad 1: input and output grids coincide
+  const int Cout = p.Cout, Cpix = p.Cpix;
+  const bf16_t* const gx = p.x;
+  const bf16_t* const gg = p.g;
   const bf16_t* zero = (const bf16_t*)g_zero_page;
 
   // ---- loader state: 2 g rows per lane; per dh window 1 x row per lane (+ rows 64..71 from wave 0) ----
@@ -295,7 +410,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9_kernel(const WgradParams p) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int m = mt + it * 32 + g_row0;
-      const bf16_t* src = (m < m_end) ? p.g + ((int64_t)m * p.Cout + co0 + g_src_el) : zero + (g_src_el & 127);
+      const bf16_t* src = (m < m_end) ? gg + ((int64_t)m * Cout + co0 + g_src_el) : zero + (g_src_el & 127);
       glds16_async(src, sG + (it * 32 + wave * 4) * RBG);
     }
 #pragma unroll
@@ -303,13 +418,13 @@ __global__ __launch_bounds__(512) void conv_wgrad9_kernel(const WgradParams p) {
       const int i = it * 64 + x_row0;                 // window row
       if (it == 1 && wave != 0) break;                // rows 64..71: one piece, wave 0 only (wave-uniform)
       const int q0 = mt + i - 1;
-      const bool in = (i < 66) && q0 >= 0 && q0 < p.M;
-      const bf16_t* src = p.x + ((int64_t)q0 * p.Cpix + ci0 + x_src_el);
+      const bool in = (i < 66) && q0 >= 0 && q0 < pM;
+      const bf16_t* src = gx + ((int64_t)q0 * Cpix + ci0 + x_src_el);
       const bf16_t* z = zero + (x_src_el & 127);
       char* dst = sX + (it * 64 + wave * 8) * RBX;
-      glds16_async((in && xh[it] != 0) ? src - (int64_t)W * p.Cpix : z, dst);               // dh = -1: row above
-      glds16_async(in ? src : z, dst + X_TILE);                                             // dh =  0
-      glds16_async((in && xh[it] != H - 1) ? src + (int64_t)W * p.Cpix : z, dst + 2 * X_TILE);  // dh = +1: row below
+      glds16_async((in && xh[it] != 0) ? src - (int64_t)W * Cpix : z, dst);               // dh = -1: row above
+      glds16_async(in ? src : z, dst + X_TILE);                                           // dh =  0
+      glds16_async((in && xh[it] != H - 1) ? src + (int64_t)W * Cpix : z, dst + 2 * X_TILE);  // dh = +1: row below
       xw[it] += BKW;
       while (xw[it] >= W) { xw[it] -= W; xh[it] += 1; }
       while (xh[it] >= H) xh[it] -= H;
@@ -318,8 +433,8 @@ __global__ __launch_bounds__(512) void conv_wgrad9_kernel(const WgradParams p) {
 
   // ---- fragment read offsets (ds_read_b64_tr_b16) ----
   const int wm = wave / WN, wn = wave % WN;
-  const int grp = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
-  const int rrow = 8 * grp + q4;
+  const int grp4 = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+  const int rrow = 8 * grp4 + q4;
   int g_off[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
@@ -352,12 +467,12 @@ __global__ __launch_bounds__(512) void conv_wgrad9_kernel(const WgradParams p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = f32_to_elem<F16>(1.0f);
 
-  // image column of the first of this lane's 8 fragment pixels (rows 8*grp .. 8*grp+7 of each 32-pixel half step)
+  // image column of the first of this lane's 8 fragment pixels (rows 8*grp4 .. 8*grp4+7 of each 32-pixel half step)
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   const int step64 = BKW % W;
   int wb[2];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) wb[kk] = (m_begin + kk * 32 + 8 * grp) % W;
+  for (int kk = 0; kk < 2; ++kk) wb[kk] = (m_begin + kk * 32 + 8 * grp4) % W;
   int mw = m_begin % W;                                       // column of the K-step's first pixel (uniform)
   auto keep_mask = [](int e) -> u32x4_t {                     // all ones except the 16 bits of element e (e >= 8: all ones)
     const unsigned keep = (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
@@ -400,11 +515,11 @@ __global__ __launch_bounds__(512) void conv_wgrad9_kernel(const WgradParams p) {
         // nine taps, the x fragments of tap t+1 in flight while tap t's MFMAs run
         bf16x8_t xf[2][FN];
         auto read_x = [&](int tap, bf16x8_t (&dst)[FN]) {
-          const int dh = tap / 3, sft = tap % 3;
+          const int dhi = tap / 3, sft = tap % 3;
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
-            const s16x4_t lo = lds_read_tr16(sX + dh * X_TILE + x_lo[sft][j] + kk * 32 * RBX);
-            const s16x4_t hi = lds_read_tr16(sX + dh * X_TILE + x_hi[sft][j] + kk * 32 * RBX);
+            const s16x4_t lo = lds_read_tr16(sX + dhi * X_TILE + x_lo[sft][j] + kk * 32 * RBX);
+            const s16x4_t hi = lds_read_tr16(sX + dhi * X_TILE + x_hi[sft][j] + kk * 32 * RBX);
             dst[j] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
           }
         };
@@ -442,45 +557,134 @@ __global__ __launch_bounds__(512) void conv_wgrad9_kernel(const WgradParams p) {
   }
 
   const int fr = lane & 15;
-  float* slab = p.slab + (int64_t)split * p.Cout * p.Ktot;
+  const int Ktot = p.Ktot, Ktap = p.Ktap;
+  if (!p.direct) {
+    float* slab = p.out + (int64_t)split * Cout * Ktot;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int co = co0 + wm * WTM + i * 16 + fr;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int kidx = t * Ktap + ci0 + wn * WTN + j * 16 + grp4 * 4;
+          *(f32x4_t*)(slab + (int64_t)co * Ktot + kidx) = acc[t][i][j];
+        }
+      if (do_colsum && grp4 == 0) p.colsum[(int64_t)split * Cout + co] = acc1[i][0];
+    }
+    return;
+  }
+  // ---- direct member: see conv_wgrad_group_kernel ----
+  const float beta = p.beta;
+  const bool want_dot = p.dotpart != nullptr;
+  float dpart[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int co = co0 + wm * WTM + i * 16 + fr;
+    const float sc = p.scale ? p.scale[co] : 1.f;
+    float d = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int kidx = t * p.Ktap + ci0 + wn * WTN + j * 16 + grp * 4;
-        *(f32x4_t*)(slab + (int64_t)co * p.Ktot + kidx) = acc[t][i][j];
+        const int kidx = t * Ktap + ci0 + wn * WTN + j * 16 + grp4 * 4;
+        const f32x4_t a = acc[t][i][j];
+        if (want_dot) {
+          const f32x4_t wv = load4_f32<F16>(p.w_fwd + (int64_t)co * Ktot + kidx);
+          d += ((wv[0] * a[0] + wv[1] * a[1]) + wv[2] * a[2]) + wv[3] * a[3];
+        }
+        f32x4_t* o = (f32x4_t*)(p.out + (int64_t)co * Ktot + kidx);
+        f32x4_t v = a * sc;
+        if (beta != 0.f) v += *o * beta;
+        *o = v;
       }
-    if (do_colsum && grp == 0) p.colsum[(int64_t)split * p.Cout + co] = acc1[i][0];
+    dpart[i] = d;
+    if (do_colsum && grp4 == 0) p.colsum[co] = acc1[i][0];
+  }
+  if (want_dot) {
+    float* red = (float*)smem;   // the loop ended on a barrier: the ring is idle
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float d = dpart[i];
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      if (grp4 == 0) red[wn * BMW + wm * WTM + i * 16 + fr] = d;
+    }
+    __syncthreads();
+    for (int c = tid; c < BMW; c += 512) {
+      float s = red[c];
+#pragma unroll
+      for (int w = 1; w < WN; ++w) s += red[w * BMW + c];
+      p.dotpart[(int64_t)tile_ci * Cout + co0 + c] = s;
+    }
   }
 }
 
-// One block per output channel: reduce the split-K slabs in a fixed order, scale, and produce affine grads.
-// The 256 threads are arranged as K4P k-lanes (float4 each) x SL split-lanes so that short rows (Ktot = 64)
-// still use the whole block; split-lane partial sums are combined through LDS in lane order (deterministic).
+// ---------------------------------------------------------------------------------------------
+// Grouped finalize: per member and output channel, reduce the split-K slabs in a fixed order, scale, and produce the
+// affine gradients; direct members only have their per-tile partial sums and column sums combined.
+// ---------------------------------------------------------------------------------------------
+struct FinItem {
+  const float* slab;      // [splitk][Cout][Ktot]  (NULL: direct member)
+  const float* colsum;    // [splitk][Cout]
+  const float* dotpart;   // direct member with BN: [ndot][Cout]
+  const bf16_t* w_fwd;
+  const float* scale;
+  const float* mean;
+  const float* invstd;
+  float* dw;
+  float* dgamma;
+  float* dbeta;
+  float beta;
+  int splitk, Cout, Ktot, map_mode, K4P, ndot, reserved;
+};
+struct FinGroup {
+  int nitems, reserved;
+  int blk_start[FIN_MAXI + 2];
+  FinItem it[FIN_MAXI];
+};
+static_assert(sizeof(FinGroup) <= 4096, "kernel-argument block too large");
+
+// Slab members: one block per output channel.  The 256 threads are arranged as K4P k-lanes (float4 each) x SL
+// split-lanes so that short rows (Ktot = 64) still use the whole block; split-lane partial sums are combined through
+// LDS in lane order (deterministic).  Direct members: one thread per channel.
 //   map_mode 0: dw index = co*Ktot + k  ([Cout][kh][kw][Cin] = channels_last view of the OIHW grad)
 //   map_mode 1: stem, k = (kh*8 + kw)*4 + c  ->  dw[co][c][kh][kw] contiguous (pads dropped)
 //   map_mode 4*cpg: grouped conv in block-diagonal form -> dw[co][kh][kw][cpg]
 template <bool F16>
-__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ slab,
-                                                             const float* __restrict__ colsum, int splitk,
-                                                             int Cout, int Ktot, const bf16_t* __restrict__ w_fwd,
-                                                             const float* __restrict__ scale,
-                                                             const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, float* dw,
-                                                             float* dgamma, float* dbeta, float beta,
-                                                             int map_mode, int K4P) {
+__global__ __launch_bounds__(256) void wgrad_finalize_group_kernel(const FinGroup grp) {
   __shared__ f32x4_t part[256];
   __shared__ float red[4];
-  const int co = blockIdx.x;
+  int idx = 0;
+#pragma unroll
+  for (int i = 1; i < FIN_MAXI; ++i) idx += ((int)blockIdx.x >= grp.blk_start[i]) ? 1 : 0;
+  const FinItem& p = grp.it[idx];
+  const int lb = (int)blockIdx.x - grp.blk_start[idx];
   const int tid = threadIdx.x;
-  const float sc = scale ? scale[co] : 1.f;
+  const int Cout = p.Cout;
+  const float beta = p.beta;
+  if (p.slab == nullptr) {
+    const int co = lb * 256 + tid;
+    if (co >= Cout) return;
+    const float cs = p.colsum[co];
+    if (p.dbeta) p.dbeta[co] = (beta != 0.f) ? beta * p.dbeta[co] + cs : cs;
+    if (p.mean && p.invstd && p.dgamma) {
+      float d = 0.f;
+      for (int t = 0; t < p.ndot; ++t) d += p.dotpart[(int64_t)t * Cout + co];
+      const float dg = (d - p.mean[co] * cs) * p.invstd[co];
+      p.dgamma[co] = (beta != 0.f) ? beta * p.dgamma[co] + dg : dg;
+    }
+    return;
+  }
+  const int co = lb;
+  const int splitk = p.splitk, Ktot = p.Ktot, K4P = p.K4P, map_mode = p.map_mode;
+  const float sc = p.scale ? p.scale[co] : 1.f;
   const int K4 = Ktot >> 2;
   const int SL = 256 / K4P;
   const int k4l = tid % K4P, spl = tid / K4P;
-  const f32x4_t* slab4 = (const f32x4_t*)slab;
+  const f32x4_t* slab4 = (const f32x4_t*)p.slab;
+  const bf16_t* w_fwd = p.w_fwd;
+  float* dw = p.dw;
   float dot = 0.f;
   for (int base = 0; base < K4; base += K4P) {
     const int k4 = base + k4l;
@@ -542,193 +746,482 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
       }
     }
   }
-  // block reduce dot; colsum over splits by wave 1
+  // block reduce dot; colsum over splits by wave 0
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
   if ((tid & 63) == 0) red[tid >> 6] = dot;
   __syncthreads();
   if (tid < 64) {
     float cs = 0.f;
-    for (int sp = tid; sp < splitk; sp += 64) cs += colsum[(int64_t)sp * Cout + co];
+    for (int sp = tid; sp < splitk; sp += 64) cs += p.colsum[(int64_t)sp * Cout + co];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cs += __shfl_down(cs, o, 64);
     if (tid == 0) {
       const float d = (red[0] + red[1]) + (red[2] + red[3]);
-      if (dbeta) dbeta[co] = (beta != 0.f) ? beta * dbeta[co] + cs : cs;
-      if (mean && invstd && dgamma) {
-        const float dg = (d - mean[co] * cs) * invstd[co];
-        dgamma[co] = (beta != 0.f) ? beta * dgamma[co] + dg : dg;
+      if (p.dbeta) p.dbeta[co] = (beta != 0.f) ? beta * p.dbeta[co] + cs : cs;
+      if (p.mean && p.invstd && p.dgamma) {
+        const float dg = (d - p.mean[co] * cs) * p.invstd[co];
+        p.dgamma[co] = (beta != 0.f) ? beta * p.dgamma[co] + dg : dg;
       }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-struct WgradPlan { int bmw, bnw, tiles_co, tiles_k, splitk, mchunk, M, Ktot, t9; };
-
-// t9_ok: the layer is a dense 3x3 / stride 1 / pad 1 conv at least 8 pixels wide (the caller checks the geometry)
-static WgradPlan plan_wgrad(int M, int Cout, int Ktap, int ntaps, bool grouped = false, bool t9_ok = false) {
-  WgradPlan w;
-  w.t9 = 0;
-  if (t9_ok && !grouped && ntaps == 9 && Cout % 128 == 0 && Ktap % 64 == 0) {
-    // measured (profiles/r01_wgrad9_bench.log): alone, 293 -> 187 us on the 200x336 FPN 3x3 and 90 -> 72 us on the
-    // 100x168 one, but ~20% slower on the small-M 3x3 layers (few one-per-CU workgroups).  Inside the captured step,
-    // where the weight gradients run on side streams next to the dgrad chain, taking it for every eligible layer was
-    // still the fastest of three settings in each of three back-to-back rounds (380.9 off / 383.6 large layers only /
-    // 386.3 img/s always), so eligibility alone decides.  TDN_WGRAD9=0 turns the kernel off.
-    const char* env = getenv("TDN_WGRAD9");   // 0: off, 1: every eligible layer, 2: only layers with >= 256 units of work
-    const int mode = env ? atoi(env) : 1;
-    const int64_t units = (int64_t)ceil_div(M, 512) * (Cout / 128) * (Ktap / 64);
-    w.t9 = mode == 2 ? (units >= 256) : (mode != 0);
-  }
-  // measured (scripts/wgrad_bench.py): 64-wide ci tiles beat 128; 256-wide co tiles (8 waves) win when Cout allows,
-  // except for the small-M 3x3 layers where the extra workgroups of the 128-wide tile matter more
-  w.bmw = (Cout % 256 == 0 && !(ntaps > 1 && M < 20000)) ? 256 : ((Cout % 128 == 0) ? 128 : 64);
-  w.bnw = (Ktap % 64 == 0) ? 64 : 32;
-  if (const char* env = getenv("TDN_WGRAD_TILE")) {   // tuning override: "BMWxBNW" with 64/128 entries
-    int a = 0, b = 0;
-    if (sscanf(env, "%dx%d", &a, &b) == 2 && (a == 64 || a == 128 || a == 256) && (b == 64 || b == 128 || b == 256) &&
-        Cout % a == 0 && Ktap % b == 0) {
-      w.bmw = a;
-      w.bnw = b;
-    }
-  }
-  if (grouped) { w.bmw = 64; w.bnw = 64; }   // one 64 x 64 diagonal block per tile
-  w.tiles_co = Cout / w.bmw;
-  w.tiles_k = ntaps * (Ktap / w.bnw);
-  if (w.t9) {   // conv_wgrad9_kernel: 128 co x 64 ci x all nine taps per workgroup
-    w.bmw = 128; w.bnw = 64;
-    w.tiles_co = Cout / 128;
-    w.tiles_k = Ktap / 64;
-  }
-  w.M = M;
-  w.Ktot = ntaps * Ktap;
-  const int tiles = w.tiles_co * w.tiles_k;
-  // Aim for ~512 workgroups (two 64 KB-LDS workgroups fit a CU) but keep each split >= 1024 pixels deep: every
-  // workgroup writes a full fp32 tile slab, so short splits turn the kernel (and the finalize pass that re-reads
-  // the slabs) into an HBM-bound slab copy.
-  int target = w.t9 ? 256 : 512, min_chunk = 512;   // the nine-tap kernel holds 150 KB of LDS: one per CU
-  if (const char* env = getenv(w.t9 ? "TDN_WGRAD9_WGS" : "TDN_WGRAD_WGS")) target = atoi(env) > 0 ? atoi(env) : target;
-  if (const char* env = getenv("TDN_WGRAD_MINCHUNK")) min_chunk = atoi(env) > 0 ? atoi(env) : min_chunk;
-  int splitk = ceil_div(target, tiles);
-  const int max_split = ceil_div(M, min_chunk) > 0 ? ceil_div(M, min_chunk) : 1;
-  if (splitk > max_split) splitk = max_split;
-  if (splitk > 256) splitk = 256;
-  if (splitk < 1) splitk = 1;
-  // splits are dealt round-robin to the 8 XCD labels (kernel's work map): keep the per-XCD load even
-  if (splitk >= 8) splitk = (splitk + 4) / 8 * 8;
-  int mchunk = ceil_div(ceil_div(M, splitk), 64) * 64;
-  splitk = ceil_div(M, mchunk);
-  w.splitk = splitk;
-  w.mchunk = mchunk;
-  return w;
-}
-
-static int64_t wgrad_ws_bytes(const WgradPlan& w, int Cout) {
-  return ((int64_t)w.splitk * Cout * w.Ktot + (int64_t)w.splitk * Cout) * 4 + 256;
-}
-
-template <int BMW, int BNW, int WM, int WN, bool F16>
-static int launch_wgrad_t(const WgradParams& p, hipStream_t stream) {
-  constexpr size_t lds = 2 * (size_t)64 * (BMW + BNW) * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<BMW, BNW, WM, WN, F16>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
-    attr_set = true;
-  }
-  const int slots = p.splitk >= 8 ? 8 * ((p.splitk + 7) / 8) : p.splitk;   // see the kernel's work map
-  dim3 grid(slots * p.tiles_co * p.tiles_k, 1, 1), block(WM * WN * 64, 1, 1);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WM, WN, F16>), grid, block, lds, stream, p);
-  TDN_LAUNCH_CHECK();
-  return 0;
-}
-
-template <int BMW, int BNW, int WM = 2, int WN = 2>
-static int launch_wgrad(const WgradParams& p, hipStream_t stream, int dtype) {
-  return dtype == TDN_F16 ? launch_wgrad_t<BMW, BNW, WM, WN, true>(p, stream)
-                          : launch_wgrad_t<BMW, BNW, WM, WN, false>(p, stream);
-}
-
-template <bool F16>
-static int launch_wgrad9_t(const WgradParams& p, hipStream_t stream) {
-  constexpr size_t lds = 2 * (size_t)(64 * 256 + 3 * 72 * 128);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel<F16>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
-    attr_set = true;
-  }
-  const int slots = p.splitk >= 8 ? 8 * ((p.splitk + 7) / 8) : p.splitk;
-  dim3 grid(slots * p.tiles_co * p.tiles_k, 1, 1), block(512, 1, 1);
-  hipLaunchKernelGGL((conv_wgrad9_kernel<F16>), grid, block, lds, stream, p);
-  TDN_LAUNCH_CHECK();
-  return 0;
-}
-
-static int launch_wgrad9(const WgradParams& p, hipStream_t stream, int dtype) {
-  return dtype == TDN_F16 ? launch_wgrad9_t<true>(p, stream) : launch_wgrad9_t<false>(p, stream);
-}
-
-static int run_wgrad(WgradParams& p, const WgradPlan& w, const void* w_fwd, const float* scale,
-                     const float* mean, const float* invstd, float* dw, float* dgamma, float* dbeta,
-                     float beta, void* workspace, int64_t workspace_bytes, int map_mode, int dtype,
-                     hipStream_t stream) {
-  TDN_CHECK(workspace_bytes >= wgrad_ws_bytes(w, p.Cout), "wgrad workspace too small: %lld < %lld",
-            (long long)workspace_bytes, (long long)wgrad_ws_bytes(w, p.Cout));
-  TDN_CHECK(((uintptr_t)workspace & 15) == 0, "wgrad workspace must be 16-byte aligned");
-  p.slab = (float*)workspace;
-  p.colsum = p.slab + (int64_t)w.splitk * p.Cout * w.Ktot;
-  p.M = w.M; p.Mchunk = w.mchunk; p.splitk = w.splitk; p.Ktot = w.Ktot;
-  p.tiles_co = w.tiles_co; p.tiles_k = w.tiles_k;
-  int rc;
-  if (w.t9) rc = launch_wgrad9(p, stream, dtype);
-  else if (w.bmw == 256 && w.bnw == 256) rc = launch_wgrad<256, 256, 4, 4>(p, stream, dtype);
-  else if (w.bmw == 256 && w.bnw == 128) rc = launch_wgrad<256, 128, 4, 4>(p, stream, dtype);
-  else if (w.bmw == 128 && w.bnw == 256) rc = launch_wgrad<128, 256, 4, 4>(p, stream, dtype);
-  else if (w.bmw == 256 && w.bnw == 64) rc = launch_wgrad<256, 64, 4, 2>(p, stream, dtype);
-  else if (w.bmw == 128 && w.bnw == 128) rc = launch_wgrad<128, 128>(p, stream, dtype);
-  else if (w.bmw == 128 && w.bnw == 64) rc = launch_wgrad<128, 64>(p, stream, dtype);
-  else if (w.bmw == 64 && w.bnw == 128) rc = launch_wgrad<64, 128>(p, stream, dtype);
-  else if (w.bmw == 64 && w.bnw == 64) rc = launch_wgrad<64, 64>(p, stream, dtype);
-  else if (w.bmw == 64 && w.bnw == 32) rc = launch_wgrad<64, 32>(p, stream, dtype);
-  else { tdn_set_error("wgrad: no kernel for tile %dx%d", w.bmw, w.bnw); return -1; }
-  if (rc) return rc;
-  int k4p = 1;
-  while (k4p < (w.Ktot >> 2) && k4p < 256) k4p <<= 1;
-  if (dtype == TDN_F16)
-    hipLaunchKernelGGL(wgrad_finalize_kernel<true>, dim3(p.Cout), dim3(256), 0, stream, p.slab, p.colsum, w.splitk,
-                       p.Cout, w.Ktot, (const bf16_t*)w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, map_mode,
-                       k4p);
-  else
-    hipLaunchKernelGGL(wgrad_finalize_kernel<false>, dim3(p.Cout), dim3(256), 0, stream, p.slab, p.colsum, w.splitk,
-                       p.Cout, w.Ktot, (const bf16_t*)w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, map_mode,
-                       k4p);
-  TDN_LAUNCH_CHECK();
-  return 0;
-}
-
+// host side: geometry, plan, launches
+// ---------------------------------------------------------------------------------------------
 // "same" convs: for k = 3 the padding is the dilation (conv3x3_group: padding = dilation, layers.py:20-32)
 static int conv_dil(int k, int pad) { return k == 3 ? pad : 1; }
 static int conv_out(int H, int k, int stride, int pad) {
   return (H + 2 * pad - (conv_dil(k, pad) * (k - 1) + 1)) / stride + 1;
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+// Tile shapes of the tap-per-tile kernel: {co, ci, wave rows, wave cols, ring depth} and, for the planner's cost
+// model, the workgroups of that shape a CU holds (LDS: NST * 64 * (co + ci) * 2 bytes of 160 KB; 32 waves) and the
+// cycles one 64-pixel K-step takes with the CU that full.  The kernel is bound by its LDS-DMA stream, and a CU moves
+// ~16 / 30 / 36 / 41 B/clk with 4 / 8 / 12 / >= 16 loading waves (scripts/trace_gemm.py), shared by its
+// workgroups.
+struct TapShape { int bmw, bnw, wm, wn, nst, per_cu, step_clk; };
+static const TapShape kTapShapes[] = {
+    {64, 32, 2, 2, 2, 6, 1800},     // 0  stem (Ktap = 32)
+    {64, 64, 2, 2, 2, 5, 2000},     // 1
+    {64, 64, 2, 2, 3, 3, 1365},     // 2
+    {128, 64, 2, 2, 2, 3, 2050},    // 3
+    {128, 64, 2, 2, 3, 2, 1640},    // 4
+    {256, 64, 4, 2, 2, 2, 2000},    // 5
+    {256, 64, 4, 2, 3, 1, 1460},    // 6
+    {128, 128, 2, 2, 2, 2, 2180},   // 7
+    {256, 128, 4, 2, 2, 1, 1750},   // 8
+};
+static const int kNumTapShapes = (int)(sizeof(kTapShapes) / sizeof(kTapShapes[0]));
+static const int kT9StepClk = 2600;   // nine-tap kernel: 72 MFMAs per wave and K-step, one 8-wave workgroup per CU
+
+struct ItemPlan {
+  // geometry
+  int Hin, Win, Cpix, Ktap, Ho, Wo, Cout, sa, M, ntaps, Ktot, tapgen, grouped, map_mode;
+  bool t9_ok, bn;
+  // decomposition
+  int variant;   // 1: nine-tap kernel, 0: tap-per-tile kernel with shape kTapShapes[shape]
+  int shape;
+  int tiles_co, tiles_k, splitk, mchunk, direct, blocks, ndot;
+  int step_clk, tmin, slots;   // cost model: cycles per K-step, fewest K-steps per split, workgroup slots of the chip
+  int64_t off_out, off_colsum, off_dot;   // workspace offsets in floats (off_out unused for direct members)
+};
+
+static int item_geometry(const tdn_wgrad_item& it, ItemPlan& g) {
+  TDN_CHECK(it.x && it.g && it.w_fwd && it.dw, "wgrad item: NULL pointer");
+  TDN_CHECK(it.N > 0 && it.H > 0 && it.W > 0, "wgrad item: bad tensor shape N=%d H=%d W=%d", it.N, it.H, it.W);
+  g.grouped = 0;
+  g.t9_ok = false;
+  g.bn = it.mean && it.invstd && it.dgamma;
+  if (it.kind == TDN_WGRAD_STEM) {
+    TDN_CHECK(it.H % 2 == 0 && it.W % 2 == 0 && it.Cout % 64 == 0, "stem wgrad: bad shape");
+    g.Hin = it.H + 6; g.Win = it.W + 8; g.Cpix = 4; g.Ktap = 32; g.Ho = it.H / 2; g.Wo = it.W / 2;
+    g.Cout = it.Cout; g.sa = 2; g.ntaps = 7; g.tapgen = 1 << 24; g.map_mode = 1;
+  } else {
+    TDN_CHECK(it.kind == TDN_WGRAD_CONV || it.kind == TDN_WGRAD_GCONV, "wgrad item: bad kind %d", it.kind);
+    const int k = it.k, stride = it.stride, pad = it.pad;
+    TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported", k);
+    TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported", stride);
+    TDN_CHECK((k == 1 && pad == 0) || (k == 3 && pad >= 1 && pad <= 32), "pad %d not supported for k=%d", pad, k);
+    TDN_CHECK(it.Cin % 64 == 0 && it.Cout % 64 == 0, "channels must be multiples of 64 (Cin=%d Cout=%d)", it.Cin,
+              it.Cout);
+    g.Hin = it.H; g.Win = it.W; g.Cpix = it.Cin; g.Ktap = it.Cin;
+    g.Ho = conv_out(it.H, k, stride, pad); g.Wo = conv_out(it.W, k, stride, pad);
+    g.Cout = it.Cout; g.sa = stride; g.ntaps = k * k;
+    g.tapgen = k | (pad << 8) | (conv_dil(k, pad) << 16);
+    g.map_mode = 0;
+    if (it.kind == TDN_WGRAD_GCONV) {
+      const int C = it.Cout, groups = it.groups;
+      TDN_CHECK(it.Cin == it.Cout, "grouped conv: Cin must equal Cout");
+      TDN_CHECK(groups > 0 && C % groups == 0 && C % 64 == 0 && (C / groups) <= 64 && 64 % (C / groups) == 0,
+                "grouped conv: need C %% 64 == 0 and channels per group dividing 64 (C=%d, groups=%d)", C, groups);
+      g.grouped = 1; g.Ktap = 64; g.map_mode = 4 * (C / groups);
+    } else {
+      g.t9_ok = (k == 3 && stride == 1 && pad == 1 && it.W >= 8 && it.Cout % 128 == 0 && it.Cin % 64 == 0);
+    }
+  }
+  TDN_CHECK(g.Ho > 0 && g.Wo > 0, "wgrad item: empty output");
+  TDN_CHECK((int64_t)it.N * g.Ho * g.Wo < (1ll << 31) / 4 && (int64_t)it.N * g.Hin * g.Win < (1ll << 31) / 4,
+            "tensor too large for 32-bit pixel indexing");
+  g.M = it.N * g.Ho * g.Wo;
+  g.Ktot = g.ntaps * g.Ktap;
+  return 0;
+}
+
+// launch key of a member: -1 nine-tap kernel, else its tile shape id
+static std::mutex g_plan_mutex;
+static std::unordered_map<uint64_t, double> g_plan_cache;   // immutable facts about shapes: split duration per group
+
+static inline int launch_key(const ItemPlan& g) { return g.variant ? -1 : g.shape; }
+
+// members of one launch: all nine-tap members / all members of one tile shape, at most WG_MAXI at a time; launch
+// order: nine-tap members first (longest workgroups); members keep their order inside a launch
+static void launch_lists(const std::vector<ItemPlan>& plans, std::vector<std::vector<int>>& lists) {
+  const int n = (int)plans.size();
+  for (int key = -1; key < kNumTapShapes; ++key) {
+    std::vector<int> cur;
+    for (int i = 0; i < n; ++i) {
+      if (launch_key(plans[i]) != key) continue;
+      cur.push_back(i);
+      if ((int)cur.size() == WG_MAXI) { lists.push_back(cur); cur.clear(); }
+    }
+    if (!cur.empty()) lists.push_back(cur);
+  }
+}
+
+// splits of one member for a target of T K-steps per split
+static void split_member(ItemPlan& g, int T) {
+  const int ksteps = ceil_div(g.M, 64);
+  if (T < 1) T = 1;
+  int splitk = (ksteps + T / 2) / T;   // nearest: 33 K-steps at T = 24 stay one split (and skip the slabs)
+  if (splitk < 1) splitk = 1;
+  if (splitk > 256) splitk = 256;
+  // splits are dealt round-robin to the 8 XCD labels (kernel's work map): keep the per-XCD load even
+  if (splitk >= 8) splitk = (splitk + 4) / 8 * 8;
+  const int mchunk = ceil_div(ceil_div(g.M, splitk), 64) * 64;
+  g.splitk = ceil_div(g.M, mchunk);
+  g.mchunk = mchunk;
+  g.blocks = wg_blocks(g.splitk, g.tiles_co * g.tiles_k);
+}
+
+// modelled cycles of the group's launches for the current splits: workgroups are handed to the chip's slots in order
+// (what the dispatcher does); a workgroup costs its K-steps plus writing its fp32 tile at ~20 B/clk; the finalize
+// pass re-reads every slab at ~4 KB/clk chip-wide
+static double model_group(const std::vector<ItemPlan>& plans, const std::vector<std::vector<int>>& lists) {
+  double total = 0.0, slab_bytes = 0.0;
+  std::vector<double> heap;
+  for (const std::vector<int>& L : lists) {
+    const int slots = plans[L[0]].slots;
+    heap.assign(slots, 0.0);   // min-heap of slot-free times (std::*_heap with greater)
+    auto cmp = [](double a, double b) { return a > b; };
+    double end = 0.0;
+    for (int i : L) {
+      const ItemPlan& g = plans[i];
+      const int tile_floats = g.variant ? 9 * 128 * 64 : kTapShapes[g.shape].bmw * kTapShapes[g.shape].bnw;
+      const double c = (double)ceil_div(g.mchunk, 64) * g.step_clk + tile_floats * 4.0 / 20.0 + 3000.0;
+      const int live = g.splitk * g.tiles_co * g.tiles_k;
+      for (int b = 0; b < live; ++b) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        const double t = heap.back() + c;
+        heap.back() = t;
+        std::push_heap(heap.begin(), heap.end(), cmp);
+        if (t > end) end = t;
+      }
+      if (!g.direct) slab_bytes += (double)g.splitk * g.Cout * g.Ktot * 4.0;
+    }
+    total += end;
+  }
+  return total + slab_bytes / 4096.0;
+}
+
+// Decomposition of a group.  Every member is cut into splits of about the same modelled duration D instead of each
+// layer filling the chip by itself; D is the candidate (a geometric grid between TDN_WGRAD_DMIN and _DMAX cycles) with
+// the smallest modelled time, subject to a floor of K-steps per split below which a split's fp32 tile — written once,
+// read once — rivals the operands it streams (nine-tap kernel: 288 KB per workgroup).
+static int plan_group(const tdn_wgrad_item* items, int n, std::vector<ItemPlan>& plans, int64_t* ws_floats) {
+  TDN_CHECK(items != nullptr && n > 0, "wgrad group: no items");
+  plans.resize(n);
+  const int t9_mode = env_int("TDN_WGRAD9", 1);   // 0: never use the nine-tap kernel
+  const int shape_env = env_int("TDN_WGRAD_SHAPE", -1);   // force kTapShapes[id] where it divides the member
+  const int s256 = env_int("TDN_WGRAD_S256", 5), s128 = env_int("TDN_WGRAD_S128", 4), s64 = env_int("TDN_WGRAD_S64", 2);
+  const int uniform = env_int("TDN_WGRAD_UNIFORM", 0);   // 1: one tile shape per group (fewest launches)
+  const int tmin_tap = env_int("TDN_WGRAD_TMIN", 24), tmin_t9 = env_int("TDN_WGRAD9_TMIN", 40);
+  const int direct_ok = env_int("TDN_WGRAD_DIRECT", 1);
+  int min_bmw = 256;
+  for (int i = 0; i < n; ++i) {
+    ItemPlan& g = plans[i];
+    if (item_geometry(items[i], g)) return -1;
+    g.variant = (g.t9_ok && t9_mode != 0) ? 1 : 0;
+    if (!g.variant && !g.grouped && g.Ktap != 32) {
+      const int b = g.Cout % 256 == 0 ? 256 : (g.Cout % 128 == 0 ? 128 : 64);
+      if (b < min_bmw) min_bmw = b;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    ItemPlan& g = plans[i];
+    if (g.variant) {
+      g.shape = -1;
+      g.tiles_co = g.Cout / 128;
+      g.tiles_k = g.Ktap / 64;
+      g.step_clk = kT9StepClk;
+      g.tmin = tmin_t9;
+      g.slots = 256;
+    } else {
+      int bmw = g.Cout % 256 == 0 ? 256 : (g.Cout % 128 == 0 ? 128 : 64);
+      if (uniform && bmw > min_bmw) bmw = min_bmw;
+      int shape = g.Ktap == 32 ? 0 : ((g.grouped || bmw == 64) ? s64 : (bmw == 128 ? s128 : s256));
+      if (shape < 0 || shape >= kNumTapShapes || g.Cout % kTapShapes[shape].bmw || g.Ktap % kTapShapes[shape].bnw ||
+          (g.grouped && (kTapShapes[shape].bmw != 64 || kTapShapes[shape].bnw != 64)))
+        shape = g.Ktap == 32 ? 0 : (g.Ktap % 64 == 0 ? 2 : 0);
+      if (shape_env >= 0 && shape_env < kNumTapShapes && !g.grouped && g.Cout % kTapShapes[shape_env].bmw == 0 &&
+          g.Ktap % kTapShapes[shape_env].bnw == 0)
+        shape = shape_env;
+      g.shape = shape;
+      const TapShape& s = kTapShapes[shape];
+      g.tiles_co = g.Cout / s.bmw;
+      g.tiles_k = g.ntaps * (g.Ktap / s.bnw);
+      g.step_clk = s.step_clk;
+      g.tmin = tmin_tap;
+      g.slots = 256 * s.per_cu;
+    }
+  }
+  std::vector<std::vector<int>> lists;
+  launch_lists(plans, lists);
+  const double dmin = env_int("TDN_WGRAD_DMIN", 40000), dmax = env_int("TDN_WGRAD_DMAX", 400000);
+  const int fixed_t = env_int("TDN_WGRAD_T", 0);   // sweeps: the same K-steps per split for every member
+  // the search below costs ~a millisecond per group: its result (D) is remembered per (member shapes, knobs)
+  uint64_t key = 1469598103934665603ull;
+  auto mix = [&key](int64_t v) { key = (key ^ (uint64_t)v) * 1099511628211ull; };
+  mix(n); mix((int64_t)dmin); mix((int64_t)dmax); mix(fixed_t);
+  for (const ItemPlan& g : plans) {
+    mix(g.M); mix(g.Cout); mix(g.Ktap); mix(g.ntaps); mix(g.variant); mix(g.shape); mix(g.tmin); mix(g.map_mode);
+    mix(g.step_clk);
+  }
+  double best = -1.0, bestD = dmin;
+  bool hit = false;
+  {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    auto itc = g_plan_cache.find(key);
+    if (itc != g_plan_cache.end()) { bestD = itc->second; hit = true; }
+  }
+  const int ncand = (fixed_t > 0 || hit) ? 0 : 24;
+  for (int c = 0; c < ncand; ++c) {
+    const double D = dmin * pow(dmax / dmin, ncand > 1 ? (double)c / (ncand - 1) : 0.0);
+    for (ItemPlan& g : plans) {
+      int T = fixed_t > 0 ? fixed_t : (int)(D / g.step_clk + 0.5);
+      if (T < g.tmin) T = g.tmin;
+      split_member(g, T);
+      g.direct = (g.splitk == 1 && g.map_mode == 0 && direct_ok) ? 1 : 0;
+    }
+    const double t = model_group(plans, lists);
+    if (best < 0 || t < best) { best = t; bestD = D; }
+  }
+  if (ncand > 0) {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    g_plan_cache[key] = bestD;
+  }
+  int64_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    ItemPlan& g = plans[i];
+    int T = fixed_t > 0 ? fixed_t : (int)(bestD / g.step_clk + 0.5);
+    if (T < g.tmin) T = g.tmin;
+    split_member(g, T);
+    g.direct = (g.splitk == 1 && g.map_mode == 0 && direct_ok) ? 1 : 0;
+    g.ndot = (g.direct && g.bn) ? g.tiles_k : 0;
+    g.off_out = off;
+    if (!g.direct) off += (int64_t)g.splitk * g.Cout * g.Ktot;
+    g.off_colsum = off;
+    off += (int64_t)g.splitk * g.Cout;
+    g.off_dot = off;
+    off += (int64_t)g.ndot * g.Cout;
+    off = (off + 63) & ~(int64_t)63;   // 256-byte alignment of every member's region
+  }
+  *ws_floats = off;
+  return 0;
+}
+
+template <int BMW, int BNW, int WM, int WN, int NST, bool F16>
+static int launch_tap_t(const WgGroup& grp, int nblocks, hipStream_t stream) {
+  constexpr size_t lds = (size_t)NST * 64 * (BMW + BNW) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_group_kernel<BMW, BNW, WM, WN, NST, F16>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_group_kernel<BMW, BNW, WM, WN, NST, F16>), dim3(nblocks), dim3(WM * WN * 64), lds,
+                     stream, grp);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool F16>
+static int launch_tap(int shape, const WgGroup& grp, int nblocks, hipStream_t stream) {
+  switch (shape) {
+    case 0: return launch_tap_t<64, 32, 2, 2, 2, F16>(grp, nblocks, stream);
+    case 1: return launch_tap_t<64, 64, 2, 2, 2, F16>(grp, nblocks, stream);
+    case 2: return launch_tap_t<64, 64, 2, 2, 3, F16>(grp, nblocks, stream);
+    case 3: return launch_tap_t<128, 64, 2, 2, 2, F16>(grp, nblocks, stream);
+    case 4: return launch_tap_t<128, 64, 2, 2, 3, F16>(grp, nblocks, stream);
+    case 5: return launch_tap_t<256, 64, 4, 2, 2, F16>(grp, nblocks, stream);
+    case 6: return launch_tap_t<256, 64, 4, 2, 3, F16>(grp, nblocks, stream);
+    case 7: return launch_tap_t<128, 128, 2, 2, 2, F16>(grp, nblocks, stream);
+    case 8: return launch_tap_t<256, 128, 4, 2, 2, F16>(grp, nblocks, stream);
+    default: tdn_set_error("wgrad: bad tile shape id %d", shape); return -1;
+  }
+}
+
+template <bool F16>
+static int launch_t9(const WgGroup& grp, int nblocks, hipStream_t stream) {
+  constexpr size_t lds = 2 * (size_t)(64 * 256 + 3 * 72 * 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_group_kernel<F16>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad9_group_kernel<F16>), dim3(nblocks), dim3(512), lds, stream, grp);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+static void fill_item(WgItem& d, const tdn_wgrad_item& it, const ItemPlan& g, float* ws) {
+  memset(&d, 0, sizeof(d));
+  d.x = (const bf16_t*)it.x; d.g = (const bf16_t*)it.g; d.w_fwd = (const bf16_t*)it.w_fwd;
+  d.scale = it.scale;
+  d.out = g.direct ? it.dw : ws + g.off_out;
+  d.colsum = ws + g.off_colsum;
+  d.dotpart = g.ndot ? ws + g.off_dot : nullptr;
+  d.Hin = g.Hin; d.Win = g.Win; d.Cpix = g.Cpix; d.Ktap = g.Ktap; d.Ho = g.Ho; d.Wo = g.Wo; d.Cout = g.Cout;
+  d.sa = g.sa; d.M = g.M; d.Mchunk = g.mchunk; d.splitk = g.splitk; d.ntaps = g.ntaps; d.Ktot = g.Ktot;
+  d.tiles_co = g.tiles_co; d.tiles_k = g.tiles_k; d.tapgen = g.tapgen; d.grouped = g.grouped; d.direct = g.direct;
+  d.beta = it.beta;
+}
+
+extern "C" int64_t tdn_wgrad_group_workspace(const tdn_wgrad_item* items, int n, int dtype) {
+  if (dtype != TDN_BF16 && dtype != TDN_F16) { tdn_set_error("dtype %d is neither TDN_BF16 nor TDN_F16", dtype); return -1; }
+  std::vector<ItemPlan> plans;
+  int64_t fl = 0;
+  if (plan_group(items, n, plans, &fl)) return -1;
+  return fl * 4 + 256;
+}
+
+extern "C" int tdn_wgrad_group_plan(const tdn_wgrad_item* items, int n, int dtype, int32_t* per_item,
+                                    int32_t* totals) {
+  TDN_CHECK(dtype == TDN_BF16 || dtype == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", dtype);
+  std::vector<ItemPlan> plans;
+  int64_t fl = 0;
+  if (plan_group(items, n, plans, &fl)) return -1;
+  std::vector<std::vector<int>> lists;
+  launch_lists(plans, lists);
+  int64_t blocks = 0, slab_kib = 0;
+  for (int i = 0; i < n; ++i) {
+    const ItemPlan& g = plans[i];
+    const int64_t slab = g.direct ? 0 : (int64_t)g.splitk * g.Cout * g.Ktot * 4 / 1024;
+    if (per_item) {
+      int32_t* o = per_item + 8 * i;
+      o[0] = g.variant; o[1] = g.variant ? 128 : kTapShapes[g.shape].bmw; o[2] = g.variant ? 64 : kTapShapes[g.shape].bnw;
+      o[3] = g.splitk; o[4] = g.mchunk; o[5] = g.direct; o[6] = g.blocks; o[7] = (int32_t)slab;
+    }
+    blocks += g.blocks;
+    slab_kib += slab;
+  }
+  if (totals) {
+    totals[0] = (int32_t)lists.size();
+    totals[1] = ceil_div(n, FIN_MAXI);
+    totals[2] = (int32_t)blocks;
+    totals[3] = (int32_t)slab_kib;
+  }
+  return 0;
+}
+
+extern "C" int tdn_wgrad_group(const tdn_wgrad_item* items, int n, void* workspace, int64_t workspace_bytes,
+                               int dtype, void* stream_) {
+  TDN_CHECK(dtype == TDN_BF16 || dtype == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", dtype);
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<ItemPlan> plans;
+  int64_t fl = 0;
+  if (plan_group(items, n, plans, &fl)) return -1;
+  TDN_CHECK(workspace != nullptr && workspace_bytes >= fl * 4, "wgrad workspace too small: %lld < %lld",
+            (long long)workspace_bytes, (long long)(fl * 4));
+  TDN_CHECK(((uintptr_t)workspace & 15) == 0, "wgrad workspace must be 16-byte aligned");
+  float* ws = (float*)workspace;
+  std::vector<std::vector<int>> lists;
+  launch_lists(plans, lists);
+  for (const std::vector<int>& L : lists) {
+    WgGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    grp.nitems = (int)L.size();
+    int blk = 0;
+    for (int j = 0; j < WG_MAXI + 2; ++j) grp.blk_start[j] = INT_MAX;
+    for (int j = 0; j < (int)L.size(); ++j) {
+      const int i = L[j];
+      grp.blk_start[j] = blk;
+      fill_item(grp.it[j], items[i], plans[i], ws);
+      blk += plans[i].blocks;
+    }
+    const ItemPlan& g0 = plans[L[0]];
+    int rc;
+    if (g0.variant) rc = dtype == TDN_F16 ? launch_t9<true>(grp, blk, stream) : launch_t9<false>(grp, blk, stream);
+    else rc = dtype == TDN_F16 ? launch_tap<true>(g0.shape, grp, blk, stream) : launch_tap<false>(g0.shape, grp, blk, stream);
+    if (rc) return rc;
+  }
+  // one finalize launch per FIN_MAXI members
+  for (int base = 0; base < n; base += FIN_MAXI) {
+    FinGroup fg;
+    memset(&fg, 0, sizeof(fg));
+    const int cnt = (n - base < FIN_MAXI) ? n - base : FIN_MAXI;
+    fg.nitems = cnt;
+    for (int j = 0; j < FIN_MAXI + 2; ++j) fg.blk_start[j] = INT_MAX;
+    int blk = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const tdn_wgrad_item& it = items[base + j];
+      const ItemPlan& g = plans[base + j];
+      FinItem& f = fg.it[j];
+      fg.blk_start[j] = blk;
+      f.slab = g.direct ? nullptr : ws + g.off_out;
+      f.colsum = ws + g.off_colsum;
+      f.dotpart = g.ndot ? ws + g.off_dot : nullptr;
+      f.w_fwd = (const bf16_t*)it.w_fwd;
+      f.scale = it.scale; f.mean = it.mean; f.invstd = it.invstd;
+      f.dw = it.dw; f.dgamma = it.dgamma; f.dbeta = it.dbeta; f.beta = it.beta;
+      f.splitk = g.splitk; f.Cout = g.Cout; f.Ktot = g.Ktot; f.map_mode = g.map_mode; f.ndot = g.ndot;
+      int k4p = 1;
+      while (k4p < (g.Ktot >> 2) && k4p < 256) k4p <<= 1;
+      f.K4P = k4p;
+      blk += g.direct ? ceil_div(g.Cout, 256) : g.Cout;
+    }
+    if (dtype == TDN_F16)
+      hipLaunchKernelGGL(wgrad_finalize_group_kernel<true>, dim3(blk), dim3(256), 0, stream, fg);
+    else
+      hipLaunchKernelGGL(wgrad_finalize_group_kernel<false>, dim3(blk), dim3(256), 0, stream, fg);
+    TDN_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---- single-layer entry points: groups of one -------------------------------------------------------------
+static tdn_wgrad_item one_item(int kind, const void* x, const void* g, const void* w_fwd, const float* scale,
+                               const float* mean, const float* invstd, float* dw, float* dgamma, float* dbeta,
+                               float beta, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                               int groups) {
+  tdn_wgrad_item it;
+  memset(&it, 0, sizeof(it));
+  it.x = x; it.g = g; it.w_fwd = w_fwd; it.scale = scale; it.mean = mean; it.invstd = invstd;
+  it.dw = dw; it.dgamma = dgamma; it.dbeta = dbeta; it.beta = beta; it.kind = kind;
+  it.N = N; it.H = H; it.W = W; it.Cin = Cin; it.Cout = Cout; it.k = k; it.stride = stride; it.pad = pad;
+  it.groups = groups;
+  return it;
+}
+// shape-only queries: the planner never dereferences the tensors
+static const void* const kShapeOnly = (const void*)(uintptr_t)256;
+
 extern "C" int64_t tdn_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int k, int stride,
                                                int pad) {
-  const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
-  const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, Cin, k * k, false, k == 3 && stride == 1 && pad == 1 && W >= 8);
-  return wgrad_ws_bytes(w, Cout);
+  const tdn_wgrad_item it = one_item(TDN_WGRAD_CONV, kShapeOnly, kShapeOnly, kShapeOnly, nullptr, nullptr, nullptr,
+                                     (float*)kShapeOnly, nullptr, nullptr, 0.f, N, H, W, Cin, Cout, k, stride, pad, 1);
+  return tdn_wgrad_group_workspace(&it, 1, TDN_BF16);
 }
 
 int tdn_wgrad_plan(int N, int H, int W, int Cin, int Cout, int k, int stride, int pad, int32_t* o) {
-  const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
-  const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, Cin, k * k, false, k == 3 && stride == 1 && pad == 1 && W >= 8);
-  o[0] = Cout; o[1] = w.Ktot; o[2] = w.M; o[3] = w.bmw; o[4] = w.bnw; o[5] = 64;
+  const tdn_wgrad_item it = one_item(TDN_WGRAD_CONV, kShapeOnly, kShapeOnly, kShapeOnly, nullptr, nullptr, nullptr,
+                                     (float*)kShapeOnly, nullptr, nullptr, 0.f, N, H, W, Cin, Cout, k, stride, pad, 1);
+  std::vector<ItemPlan> plans;
+  int64_t fl = 0;
+  if (plan_group(&it, 1, plans, &fl)) return -1;
+  const ItemPlan& w = plans[0];
+  o[0] = Cout; o[1] = w.Ktot; o[2] = w.M; o[3] = w.variant ? 128 : kTapShapes[w.shape].bmw;
+  o[4] = w.variant ? 64 : kTapShapes[w.shape].bnw; o[5] = 64;
   o[6] = w.tiles_co * w.tiles_k; o[7] = w.splitk; o[8] = 1; o[9] = 1; o[10] = k * k; o[11] = w.splitk;
-  o[12] = w.mchunk; o[13] = Ho; o[14] = Wo; o[15] = w.M;
+  o[12] = w.mchunk; o[13] = w.Ho; o[14] = w.Wo; o[15] = w.M;
   return 0;
 }
 
@@ -737,74 +1230,42 @@ extern "C" int tdn_conv2d_wgrad(const void* x, const void* g, const void* w_fwd,
                                 float* dbeta, float beta, int N, int H, int W, int Cin, int Cout, int k,
                                 int stride, int pad, void* workspace, int64_t workspace_bytes, int dtype,
                                 void* stream) {
-  TDN_CHECK(dtype == TDN_BF16 || dtype == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", dtype);
   TDN_CHECK(x && g && w_fwd && dw && workspace, "tdn_conv2d_wgrad: NULL pointer");
-  TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported", k);
-  TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported", stride);
-  TDN_CHECK((k == 1 && pad == 0) || (k == 3 && pad >= 1 && pad <= 32), "pad %d not supported for k=%d", pad, k);
-  TDN_CHECK(Cin % 64 == 0 && Cout % 64 == 0, "channels must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
-  const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
-  const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, Cin, k * k, false, k == 3 && stride == 1 && pad == 1 && W >= 8);
-  WgradParams p;
-  p.x = (const bf16_t*)x; p.g = (const bf16_t*)g; p.grouped = 0;
-  p.Hin = H; p.Win = W; p.Cpix = Cin; p.Ktap = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.sa = stride;
-  p.ntaps = k * k;
-  for (int kh = 0; kh < k; ++kh)
-    for (int kw = 0; kw < k; ++kw) p.taps[kh * k + kw] = (kh * conv_dil(k, pad) - pad + 64) | ((kw * conv_dil(k, pad) - pad + 64) << 8);
-  return run_wgrad(p, w, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes, 0,
-                   dtype, (hipStream_t)stream);
+  const tdn_wgrad_item it = one_item(TDN_WGRAD_CONV, x, g, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, N, H,
+                                     W, Cin, Cout, k, stride, pad, 1);
+  return tdn_wgrad_group(&it, 1, workspace, workspace_bytes, dtype, stream);
 }
 
 // Grouped conv weight gradient (see tdn_gconv2d_fwd): per 64-channel block a dense 64 x (taps * 64) product, of which
 // the finalize pass keeps each output channel's own group: dw fp32 [C][k][k][cpg].
 extern "C" int64_t tdn_gconv2d_wgrad_workspace(int N, int H, int W, int C, int groups, int k, int stride, int pad) {
-  const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
-  const WgradPlan w = plan_wgrad(N * Ho * Wo, C, 64, k * k, true);
-  return wgrad_ws_bytes(w, C);
+  const tdn_wgrad_item it = one_item(TDN_WGRAD_GCONV, kShapeOnly, kShapeOnly, kShapeOnly, nullptr, nullptr, nullptr,
+                                     (float*)kShapeOnly, nullptr, nullptr, 0.f, N, H, W, C, C, k, stride, pad, groups);
+  return tdn_wgrad_group_workspace(&it, 1, TDN_BF16);
 }
 
 extern "C" int tdn_gconv2d_wgrad(const void* x, const void* g, const void* w_fwd, const float* scale,
                                  const float* mean, const float* invstd, float* dw, float* dgamma, float* dbeta,
                                  float beta, int N, int H, int W, int C, int groups, int k, int stride, int pad,
                                  void* workspace, int64_t workspace_bytes, int dtype, void* stream) {
-  TDN_CHECK(dtype == TDN_BF16 || dtype == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", dtype);
   TDN_CHECK(x && g && w_fwd && dw && workspace, "tdn_gconv2d_wgrad: NULL pointer");
-  TDN_CHECK(k == 1 || k == 3, "kernel size %d not supported", k);
-  TDN_CHECK(stride == 1 || stride == 2, "stride %d not supported", stride);
-  TDN_CHECK((k == 1 && pad == 0) || (k == 3 && pad >= 1 && pad <= 32), "pad %d not supported for k=%d", pad, k);
-  TDN_CHECK(groups > 0 && C % groups == 0 && C % 64 == 0 && (C / groups) <= 64 && 64 % (C / groups) == 0,
-            "grouped conv: need C %% 64 == 0 and channels per group dividing 64 (C=%d, groups=%d)", C, groups);
-  const int Ho = conv_out(H, k, stride, pad), Wo = conv_out(W, k, stride, pad);
-  const WgradPlan w = plan_wgrad(N * Ho * Wo, C, 64, k * k, true);
-  WgradParams p;
-  p.x = (const bf16_t*)x; p.g = (const bf16_t*)g; p.grouped = 1;
-  p.Hin = H; p.Win = W; p.Cpix = C; p.Ktap = 64; p.Ho = Ho; p.Wo = Wo; p.Cout = C; p.sa = stride;
-  p.ntaps = k * k;
-  for (int kh = 0; kh < k; ++kh)
-    for (int kw = 0; kw < k; ++kw) p.taps[kh * k + kw] = (kh * conv_dil(k, pad) - pad + 64) | ((kw * conv_dil(k, pad) - pad + 64) << 8);
-  return run_wgrad(p, w, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes,
-                   4 * (C / groups), dtype, (hipStream_t)stream);
+  const tdn_wgrad_item it = one_item(TDN_WGRAD_GCONV, x, g, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, N, H,
+                                     W, C, C, k, stride, pad, groups);
+  return tdn_wgrad_group(&it, 1, workspace, workspace_bytes, dtype, stream);
 }
 
 extern "C" int64_t tdn_stem_conv_wgrad_workspace(int N, int H, int W, int Cout) {
-  const WgradPlan w = plan_wgrad(N * (H / 2) * (W / 2), Cout, 32, 7);
-  return wgrad_ws_bytes(w, Cout);
+  const tdn_wgrad_item it = one_item(TDN_WGRAD_STEM, kShapeOnly, kShapeOnly, kShapeOnly, nullptr, nullptr, nullptr,
+                                     (float*)kShapeOnly, nullptr, nullptr, 0.f, N, H, W, 3, Cout, 7, 2, 3, 1);
+  return tdn_wgrad_group_workspace(&it, 1, TDN_BF16);
 }
 
 extern "C" int tdn_stem_conv_wgrad(const void* xp, const void* g, const void* w_stem, const float* scale,
                                    const float* mean, const float* invstd, float* dw, float* dgamma,
                                    float* dbeta, float beta, int N, int H, int W, int Cout, void* workspace,
                                    int64_t workspace_bytes, int dtype, void* stream) {
-  TDN_CHECK(dtype == TDN_BF16 || dtype == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", dtype);
   TDN_CHECK(xp && g && w_stem && dw && workspace, "tdn_stem_conv_wgrad: NULL pointer");
-  TDN_CHECK(H % 2 == 0 && W % 2 == 0 && Cout % 64 == 0, "stem wgrad: bad shape");
-  const int Ho = H / 2, Wo = W / 2;
-  const WgradPlan w = plan_wgrad(N * Ho * Wo, Cout, 32, 7);
-  WgradParams p;
-  p.x = (const bf16_t*)xp; p.g = (const bf16_t*)g; p.grouped = 0;
-  p.Hin = H + 6; p.Win = W + 8; p.Cpix = 4; p.Ktap = 32; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.sa = 2;
-  p.ntaps = 7;
-  for (int kh = 0; kh < 7; ++kh) p.taps[kh] = (kh + 64) | ((0 + 64) << 8);
-  return run_wgrad(p, w, w_stem, scale, mean, invstd, dw, dgamma, dbeta, beta, workspace, workspace_bytes, 1,
-                   dtype, (hipStream_t)stream);
+  const tdn_wgrad_item it = one_item(TDN_WGRAD_STEM, xp, g, w_stem, scale, mean, invstd, dw, dgamma, dbeta, beta, N,
+                                     H, W, 3, Cout, 7, 2, 3, 1);
+  return tdn_wgrad_group(&it, 1, workspace, workspace_bytes, dtype, stream);
 }

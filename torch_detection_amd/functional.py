@@ -406,78 +406,133 @@ def join_branches(device):
     _side_refs.pop(key, None)
 
 
-def unit_wgrad(u, x_in, g, img_hw=None):
-    """Gradients aligned with ``u.params()``.  With a gradient sink attached (dp.py) the kernels write straight
-    into the bucket views and ``None`` is returned for autograd (``param.grad`` already aliases the views)."""
-    sink = u.sink
-    dev = g.device
-    dg = db = None
-    gn_affine = None
-    dyn = u.gn or u.bnt
-    if dyn:
-        g = _gn_dz(u, g)                       # dL/dz; the affine gradients come from the norm kernel
-        gn_affine = _gn_store(u)[(u, 'dz')][2:]
-    if sink is not None:
-        dw, d0, d1 = sink
+def _t9_eligible(u, x_in):
+    """Mirror of the library's choice of the nine-tap kernel (csrc/conv_wgrad.hip: item_geometry) — only used to put
+    those members into a launch group (and side stream) of their own, never for correctness."""
+    return (u.k == 3 and u.stride == 1 and u.pad == 1 and u.groups == 1 and not u.is_stem and u.Cout % 128 == 0
+            and u.Cin % 64 == 0 and x_in.shape[2] >= 8)
+
+
+class WgradQueue(object):
+    """Weight-gradient work of one backward pass, collected and launched per GROUP (a ResNet stage, the FPN's output
+    convs, its laterals): ``add`` allocates the outputs and records one member, ``flush`` enqueues the members as
+    grouped launches (ops.wgrad_group) on side streams — the nine-tap-eligible 3x3 convs as one group, everything
+    else as another — after an event on the current stream (every recorded ``g`` exists by then).
+
+    Within a backward pass the weight gradients depend only on tensors that already exist (the saved forward input
+    and the activation gradient g), while the dgrad chain that produces the next g is the critical path; a layer's
+    weight gradient alone cannot fill 256 CUs without cutting its pixel range into many fp32 partial slabs, a stage's
+    can.  TDN_WGRAD_GROUP=0 flushes after every member (one launch group per layer)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.members = []      # (unit, item, side-stream group tag)
+        self.per_layer = os.environ.get('TDN_WGRAD_GROUP', '1') == '0'
+
+    def add(self, u, x_in, g, img_hw=None):
+        """Gradients aligned with ``u.params()`` (written when the group is flushed).  With a gradient sink attached
+        (dp.py) the kernels write straight into the bucket views and ``None`` is returned for autograd
+        (``param.grad`` already aliases the views)."""
+        sink = u.sink
+        dev = g.device
+        dg = db = None
+        gn_affine = None
+        dyn = u.gn or u.bnt
         if dyn:
-            pass                                # dgamma / dbeta were written into the sink by _gn_dz
-        elif u.bn is not None:
-            dg, db = d0, d1
+            g = _gn_dz(u, g)                       # dL/dz; the affine gradients come from the norm kernel
+            gn_affine = _gn_store(u)[(u, 'dz')][2:]
+        if sink is not None:
+            dw, d0, d1 = sink
+            if dyn:
+                pass                                # dgamma / dbeta were written into the sink by _gn_dz
+            elif u.bn is not None:
+                dg, db = d0, d1
+            else:
+                db = d0
         else:
-            db = d0
-    else:
-        # outputs are allocated on the main stream (their consumers live there); only the kernels move
-        dw = torch.empty((u.Cout, 3, 7, 7) if u.is_stem else (u.Cout, u.k, u.k, u.Cin // u.groups),
-                         dtype=torch.float32, device=dev)
-        if u.bn is not None and not dyn:
-            dg = torch.empty(u.Cout, dtype=torch.float32, device=dev)
-        if (u.bn is not None and not dyn) or u.conv.bias is not None:
-            db = torch.empty(u.Cout, dtype=torch.float32, device=dev)
-    side = _side_stream(dev)
-    prev = None
-    if side is not None:
-        ev = torch.cuda.Event()
-        ev.record()               # g (and everything before it) is ready on the main stream
-        side.wait_event(ev)
-        # keep the operands' memory from being recycled while the side stream still reads it (see _side_refs)
-        _side_refs.setdefault((dev.index, torch._C._cuda_getCurrentRawStream(dev.index)), []).extend((x_in, g))
-        prev = _lib.set_stream_override(side.cuda_stream)
-    try:
+            # outputs are allocated on the main stream (their consumers live there); only the kernels move
+            dw = torch.empty((u.Cout, 3, 7, 7) if u.is_stem else (u.Cout, u.k, u.k, u.Cin // u.groups),
+                             dtype=torch.float32, device=dev)
+            if u.bn is not None and not dyn:
+                dg = torch.empty(u.Cout, dtype=torch.float32, device=dev)
+            if (u.bn is not None and not dyn) or u.conv.bias is not None:
+                db = torch.empty(u.Cout, dtype=torch.float32, device=dev)
+        want_db = db is not None
         if u.is_stem:
-            dw, dg, db = ops.stem_conv_wgrad(x_in, g, u.w_fwd, img_hw, u.scale, u.mean, u.invstd, dw, dg, db,
-                                             want_dbeta=db is not None)
+            it, dw, dg, db = ops.stem_conv_wgrad_item(x_in, g, u.w_fwd, img_hw, u.scale, u.mean, u.invstd, dw, dg, db,
+                                                      want_dbeta=want_db)
             dw_view = dw
         else:
             dw4 = dw.view(u.Cout, u.k, u.k, u.Cin // u.groups)
-            # every output tensor of this call was allocated above, on the main stream, and stays referenced: the
-            # kernels run on the side stream, so nothing they write may be a temporary of the call
             if u.groups > 1:
-                dw4, dg, db = ops.gconv2d_wgrad(x_in, g, u.w_fwd, u.groups, u.k, u.stride, u.pad, u.scale, u.mean,
-                                                u.invstd, dw4, dg, db, want_dbeta=db is not None)
+                it, dw4, dg, db = ops.gconv2d_wgrad_item(x_in, g, u.w_fwd, u.groups, u.k, u.stride, u.pad, u.scale,
+                                                         u.mean, u.invstd, dw4, dg, db, want_dbeta=want_db)
             else:
-                dw4, dg, db = ops.conv2d_wgrad(x_in, g, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.mean, u.invstd,
-                                               dw4, dg, db, want_dbeta=db is not None)
+                it, dw4, dg, db = ops.conv2d_wgrad_item(x_in, g, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.mean,
+                                                        u.invstd, dw4, dg, db, want_dbeta=want_db)
             # 1x1: [Cout,1,1,Cin] is byte-identical to the contiguous OIHW parameter -> view, so autograd's
             # layout contract holds and AccumulateGrad does not copy
             dw_view = dw4.view(u.Cout, u.Cin // u.groups, 1, 1) if u.k == 1 else dw4.permute(0, 3, 1, 2)
-    finally:
-        if side is not None:
-            _lib.set_stream_override(prev)
-    if u.on_grads is not None:
-        u.on_grads(u, side)
-    if sink is not None:
-        return [None] * len(u.params())
-    if u.bias_and_norm:
-        # dyn: db = sum of dL/dz = the bias gradient.  Folded eval-mode BN: dL/dz = g * scale, so the bias gradient is
-        # scale * dbeta — left as None here and filled in by the caller once the side stream has been joined
-        return [dw_view, db, gn_affine[0], gn_affine[1]] if dyn else [dw_view, None, dg, db]
-    if dyn:
-        return [dw_view, gn_affine[0], gn_affine[1]]
-    if u.bn is not None:
-        return [dw_view, dg, db]
-    if u.conv.bias is not None:
-        return [dw_view, db]
-    return [dw_view]
+        # every tensor a member's raw pointers refer to stays referenced until the side streams have been joined
+        # (the kernels run later, on another stream: nothing they touch may be recycled before; see _side_refs)
+        key = (dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
+        _side_refs.setdefault(key, []).extend(t for t in (x_in, g, dw, dg, db, u.w_fwd, u.scale, u.mean, u.invstd)
+                                              if t is not None)
+        self.members.append((u, it, 1 if _t9_eligible(u, x_in) else 0))
+        if self.per_layer:
+            self.flush()
+        if sink is not None:
+            return [None] * len(u.params())
+        if u.bias_and_norm:
+            # dyn: db = sum of dL/dz = the bias gradient.  Folded eval-mode BN: dL/dz = g * scale, so the bias
+            # gradient is scale * dbeta — left as None here and filled in by the caller once the side stream has
+            # been joined
+            return [dw_view, db, gn_affine[0], gn_affine[1]] if dyn else [dw_view, None, dg, db]
+        if dyn:
+            return [dw_view, gn_affine[0], gn_affine[1]]
+        if u.bn is not None:
+            return [dw_view, dg, db]
+        if u.conv.bias is not None:
+            return [dw_view, db]
+        return [dw_view]
+
+    def flush(self):
+        """Enqueue everything recorded so far."""
+        if not self.members:
+            return
+        members, self.members = self.members, []
+        dev = self.device
+        ev = None
+        for tag in (1, 0):
+            grp = [(u, it) for u, it, t in members if t == tag]
+            if not grp:
+                continue
+            side = _side_stream(dev)
+            prev = None
+            if side is not None:
+                if ev is None:
+                    ev = torch.cuda.Event()
+                    ev.record()           # every g recorded so far is ready on the main stream
+                side.wait_event(ev)
+                prev = _lib.set_stream_override(side.cuda_stream)
+            try:
+                ops.wgrad_group([it for _, it in grp], grp[0][0].dtype, dev)
+            finally:
+                if side is not None:
+                    _lib.set_stream_override(prev)
+            for u, _ in grp:
+                if u.on_grads is not None:
+                    u.on_grads(u, side)
+
+
+def unit_wgrad(u, x_in, g, img_hw=None, queue=None):
+    """Weight / affine gradients of one unit: recorded in ``queue`` (launched at its next flush), or launched now."""
+    if queue is not None:
+        return queue.add(u, x_in, g, img_hw)
+    q = WgradQueue(g.device)
+    grads = q.add(u, x_in, g, img_hw)
+    q.flush()
+    return grads
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -656,7 +711,7 @@ def _block_fwd(x, b):
     return out, (x, h1, None, out)
 
 
-def _block_bwd(b, saved, g, extra, mask_src, need_dx):
+def _block_bwd(b, saved, g, extra, mask_src, need_dx, wq=None):
     """g: gradient w.r.t. the block's pre-ReLU output, already masked by (out > 0).
     extra: external gradient w.r.t. the block INPUT to fold in (e.g. the FPN's gradient of a stage output).
     mask_src: if given, the returned dx is masked by (mask_src > 0) — i.e. it already is the masked ``g`` of the
@@ -668,16 +723,16 @@ def _block_bwd(b, saved, g, extra, mask_src, need_dx):
         with branch(g.device, b.ud, (g, extra) if extra is not None else (g,)) as br:
             t = unit_dgrad(b.ud, g, _hw(x), extra, ADD_SAME)   # beside the conv3 -> conv2 dgrads of the main path
     if b.kind == 'bottleneck':
-        grads[b.u3] = unit_wgrad(b.u3, h2, g)
+        grads[b.u3] = unit_wgrad(b.u3, h2, g, queue=wq)
         g2 = unit_dgrad(b.u3, g, _hw(h2), mask_src=h2)
-        grads[b.u2] = unit_wgrad(b.u2, h1, g2)
+        grads[b.u2] = unit_wgrad(b.u2, h1, g2, queue=wq)
         g1 = unit_dgrad(b.u2, g2, _hw(h1), mask_src=h1)
     else:
-        grads[b.u2] = unit_wgrad(b.u2, h1, g)
+        grads[b.u2] = unit_wgrad(b.u2, h1, g, queue=wq)
         g1 = unit_dgrad(b.u2, g, _hw(h1), mask_src=h1)
-    grads[b.u1] = unit_wgrad(b.u1, x, g1)
+    grads[b.u1] = unit_wgrad(b.u1, x, g1, queue=wq)
     if b.ud is not None:
-        grads[b.ud] = unit_wgrad(b.ud, x, g)
+        grads[b.ud] = unit_wgrad(b.ud, x, g, queue=wq)
     dx = None
     if need_dx:
         if b.ud is not None:
@@ -759,6 +814,7 @@ class SeqNetFunction(torch.autograd.Function):
         unit_grads = {}
         need_net_dx = ctx.needs_input_grad[1] and net.stem is None
         g = None
+        wq = WgradQueue(ctx.dev)
         for bi in reversed(range(len(net.blocks))):
             b, sv = net.blocks[bi], saved[bi]
             if g is None:
@@ -769,17 +825,20 @@ class SeqNetFunction(torch.autograd.Function):
             extra = ext.get(bi - 1) if bi > 0 else None
             mask_src = saved[bi - 1][3] if bi > 0 else None
             need_dx = bi > 0 or net.stem is not None or need_net_dx
-            g, gr = _block_bwd(b, sv, g, extra, mask_src, need_dx)
+            g, gr = _block_bwd(b, sv, g, extra, mask_src, need_dx, wq)
             unit_grads.update(gr)
+            if b.ud is not None:
+                wq.flush()    # first block of a stage (resnet.py:130-136): the stage's weight gradients as one group
         dx_in = None
         if net.stem is not None:
             if g is not None:
                 H, W = st['img_hw']
                 ds = ops.maxpool3x3s2_bwd(g, st['idx'], (H // 2, W // 2), st['s'])
-                unit_grads[net.stem] = unit_wgrad(net.stem, st['xp'], ds, (H, W))
+                unit_grads[net.stem] = unit_wgrad(net.stem, st['xp'], ds, (H, W), queue=wq)
             # the image itself gets no gradient (the reference never needs one; SURVEY §8(d): -5.06 GFLOP)
         elif need_net_dx and g is not None:
             dx_in = _as_nchw(g)
+        wq.flush()
         flat = []
         for u in net.units():
             flat += unit_grads.get(u, [None] * len(u.params()))
@@ -874,6 +933,7 @@ class FPNFunction(torch.autograd.Function):
 
         unit_grads = {}
         dx = [None] * net.num_ins
+        wq = WgradQueue(dev)
         if net.num_outs > nlat:
             if not net.add_extra_convs:
                 for j in range(net.num_outs - 1, nlat - 1, -1):
@@ -883,7 +943,7 @@ class FPNFunction(torch.autograd.Function):
                 for j in range(net.num_outs - 1, nlat - 1, -1):
                     gj = d[j] if d[j] is not None else zeros(j)
                     xin = ctx.extra_in[j - nlat]
-                    unit_grads[net.fpn[j]] = unit_wgrad(net.fpn[j], xin, gj)
+                    unit_grads[net.fpn[j]] = unit_wgrad(net.fpn[j], xin, gj, queue=wq)
                     if j > nlat:
                         # input was relu(out[j-1]) written back in place: mask by the (ReLU'd) saved tensor
                         d[j - 1] = unit_dgrad(net.fpn[j], gj, _hw(xin), d[j - 1], ADD_SAME, xin)
@@ -892,13 +952,18 @@ class FPNFunction(torch.autograd.Function):
                         if ctx.needs_input_grad[1 + k]:
                             dx[k] = unit_dgrad(net.fpn[j], gj, _hw(xin))
         dL = [None] * nlat
+        # the output convs' weight gradients need nothing this pass still has to compute (d and the saved laterals):
+        # one group, launched before the dgrad chain starts; the laterals' follow as a second group behind it
+        gis = [d[i] if d[i] is not None else zeros(i) for i in range(nlat)]
         for i in range(nlat):
-            gi = d[i] if d[i] is not None else zeros(i)
-            unit_grads[net.fpn[i]] = unit_wgrad(net.fpn[i], lat[i], gi)
+            unit_grads[net.fpn[i]] = unit_wgrad(net.fpn[i], lat[i], gis[i], queue=wq)
+        wq.flush()
+        for i in range(nlat):
+            gi = gis[i]
             dL[i] = unit_dgrad(net.fpn[i], gi, _hw(lat[i]), dL[i - 1] if i > 0 else None, ADD_SUMPOOL2)
             # level i's lateral gradients need only dL[i]: they run beside the remaining (coarser, smaller) output
             # convs' dgrad chain; the coarsest one, whose result the backbone's backward starts from, stays inline
-            unit_grads[net.lat[i]] = unit_wgrad(net.lat[i], xs[i], dL[i])
+            unit_grads[net.lat[i]] = unit_wgrad(net.lat[i], xs[i], dL[i], queue=wq)
             k = i + net.start_level
             if ctx.needs_input_grad[1 + k]:
                 if i < nlat - 1:
@@ -907,6 +972,7 @@ class FPNFunction(torch.autograd.Function):
                 else:
                     t = unit_dgrad(net.lat[i], dL[i], _hw(xs[i]), dx[k], ADD_SAME)
                 dx[k] = t
+        wq.flush()
         flat = []
         for u in net.units():
             flat += unit_grads.get(u, [None] * len(u.params()))
@@ -982,18 +1048,24 @@ class PAPathFunction(torch.autograd.Function):
                 d[j - 1] = ops.subsample2_bwd(d[j], _hw(outs[j - 1]), d[j - 1])
         unit_grads = {}
         dP = [None] * n
+        wq = WgradQueue(dev)
+
+        def masked(g_, y_, u_):   # backward of the unit's activation from its saved output: ReLU, or ReLU6 (0 < y < 6)
+            return ops.act_mask(g_, y_, 6.0) if u_.act6 else ops.add_relu_mask(g_, None, y_)
+
         for i in range(n - 1, 0, -1):
             u1, u2 = net.pa1[i - 1], net.pa2[i - 1]
             g = d[i] if d[i] is not None else torch.zeros_like(outs[i])
             if u2.relu:
-                g = ops.add_relu_mask(g, None, outs[i])
-            unit_grads[u2] = unit_wgrad(u2, ctx.s_saved[i - 1], g)
+                g = masked(g, outs[i], u2)
+            unit_grads[u2] = unit_wgrad(u2, ctx.s_saved[i - 1], g, queue=wq)
             ds = unit_dgrad(u2, g, _hw(ctx.s_saved[i - 1]))
             dP[i] = ds
-            dt = ops.add_relu_mask(ds, None, ctx.t_saved[i - 1]) if u1.relu else ds
-            unit_grads[u1] = unit_wgrad(u1, outs[i - 1], dt)
+            dt = masked(ds, ctx.t_saved[i - 1], u1) if u1.relu else ds
+            unit_grads[u1] = unit_wgrad(u1, outs[i - 1], dt, queue=wq)
             d[i - 1] = unit_dgrad(u1, dt, _hw(outs[i - 1]), d[i - 1], ADD_SAME)
         dP[0] = d[0]
+        wq.flush()
         flat = []
         for u in net.units():
             flat += unit_grads.get(u, [None] * len(u.params()))

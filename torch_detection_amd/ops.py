@@ -175,12 +175,56 @@ def _workspace(nbytes, device):
     return buf
 
 
-def conv2d_wgrad(x, g, w_fwd, k, stride, pad, scale=None, mean=None, invstd=None, dw=None, dgamma=None,
-                 dbeta=None, beta=0.0, want_dbeta=True):
-    """Weight + affine grads. dw: fp32 [Cout,k,k,Cin] (written, or accumulated when beta=1).  ``want_dbeta=False``:
-    the per-channel sum of g is not wanted (a conv without bias / with GroupNorm) — nothing is allocated for it.
-    (A temporary here would be written by the finalize kernel on whatever stream the call is routed to and could be
-    recycled by the allocator before that kernel has run.)"""
+WGRAD_CONV, WGRAD_STEM, WGRAD_GCONV = 0, 1, 2
+
+
+def wgrad_item(kind, x, g, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, N, H, W, Cin, Cout, k, stride, pad,
+               groups=1):
+    """One member of a grouped weight-gradient launch (``tdn_wgrad_item``); the tensors must stay referenced by the
+    caller until the launch has been enqueued AND has run (they are raw pointers here)."""
+    it = _lib.WgradItem()
+    it.x, it.g, it.w_fwd = x.data_ptr(), g.data_ptr(), w_fwd.data_ptr()
+    it.scale = scale.data_ptr() if scale is not None else None
+    it.mean = mean.data_ptr() if mean is not None else None
+    it.invstd = invstd.data_ptr() if invstd is not None else None
+    it.dw = dw.data_ptr()
+    it.dgamma = dgamma.data_ptr() if dgamma is not None else None
+    it.dbeta = dbeta.data_ptr() if dbeta is not None else None
+    it.beta = float(beta)
+    it.kind = kind
+    it.N, it.H, it.W, it.Cin, it.Cout, it.k, it.stride, it.pad, it.groups = N, H, W, Cin, Cout, k, stride, pad, groups
+    return it
+
+
+def wgrad_group(items, dtype, device):
+    """Launch the weight / affine gradients of all ``items`` (``wgrad_item``) as one group on the routed stream:
+    tdn_wgrad_group — a few gradient launches spanning every member + one finalize launch."""
+    n = len(items)
+    if n == 0:
+        return
+    arr = (_lib.WgradItem * n)(*items)
+    lib = _lib.load()
+    code = dtype_code(dtype)
+    nbytes = lib.tdn_wgrad_group_workspace(arr, n, code)
+    if nbytes < 0:
+        _lib.check(-1, "tdn_wgrad_group_workspace")
+    ws = _workspace(nbytes, device)
+    _lib.check(lib.tdn_wgrad_group(arr, n, _ptr(ws), ws.numel(), code, _lib.stream_ptr()), "tdn_wgrad_group")
+
+
+def wgrad_group_plan(items, dtype=BF16):
+    """Host-only: (per_item rows of 8 ints, totals of 4 ints) — see tdn_wgrad_group_plan in include/tdn.h."""
+    n = len(items)
+    arr = (_lib.WgradItem * n)(*items)
+    per = (ctypes.c_int32 * (8 * n))()
+    tot = (ctypes.c_int32 * 4)()
+    _lib.check(_lib.load().tdn_wgrad_group_plan(arr, n, dtype_code(dtype), per, tot), "tdn_wgrad_group_plan")
+    return [list(per[8 * i:8 * i + 8]) for i in range(n)], list(tot)
+
+
+def conv2d_wgrad_item(x, g, w_fwd, k, stride, pad, scale=None, mean=None, invstd=None, dw=None, dgamma=None,
+                      dbeta=None, beta=0.0, want_dbeta=True):
+    """Validate one conv's weight-gradient operands, allocate missing outputs; returns (item, dw, dgamma, dbeta)."""
     _chk_act(x, "x")
     _chk_act(g, "g", None, x.dtype)
     if w_fwd.dtype != x.dtype:
@@ -202,12 +246,20 @@ def conv2d_wgrad(x, g, w_fwd, k, stride, pad, scale=None, mean=None, invstd=None
         dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
     for t, n in ((scale, "scale"), (mean, "mean"), (invstd, "invstd"), (dgamma, "dgamma"), (dbeta, "dbeta")):
         _chk_vec(t, n, Cout)
-    lib = _lib.load()
-    nbytes = lib.tdn_conv2d_wgrad_workspace(N, H, W, Cin, Cout, k, stride, pad)
-    ws = _workspace(nbytes, dev)
-    _lib.check(lib.tdn_conv2d_wgrad(_ptr(x), _ptr(g), _ptr(w_fwd), _ptr(scale), _ptr(mean), _ptr(invstd), _ptr(dw),
-                                    _ptr(dgamma), _ptr(dbeta), float(beta), N, H, W, Cin, Cout, k, stride, pad,
-                                    _ptr(ws), ws.numel(), dtype_code(x.dtype), _lib.stream_ptr()), "tdn_conv2d_wgrad")
+    it = wgrad_item(WGRAD_CONV, x, g, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, N, H, W, Cin, Cout, k,
+                    stride, pad)
+    return it, dw, dgamma, dbeta
+
+
+def conv2d_wgrad(x, g, w_fwd, k, stride, pad, scale=None, mean=None, invstd=None, dw=None, dgamma=None,
+                 dbeta=None, beta=0.0, want_dbeta=True):
+    """Weight + affine grads. dw: fp32 [Cout,k,k,Cin] (written, or accumulated when beta=1).  ``want_dbeta=False``:
+    the per-channel sum of g is not wanted (a conv without bias / with GroupNorm) — nothing is allocated for it.
+    (A temporary here would be written by the finalize kernel on whatever stream the call is routed to and could be
+    recycled by the allocator before that kernel has run.)"""
+    it, dw, dgamma, dbeta = conv2d_wgrad_item(x, g, w_fwd, k, stride, pad, scale, mean, invstd, dw, dgamma, dbeta,
+                                              beta, want_dbeta)
+    wgrad_group([it], x.dtype, x.device)
     return dw, dgamma, dbeta
 
 
@@ -241,8 +293,8 @@ def stem_conv_fwd(xp, w_stem, hw, scale=None, shift=None, relu=True, out_f32=Fal
     return y
 
 
-def stem_conv_wgrad(xp, g, w_stem, hw, scale=None, mean=None, invstd=None, dw=None, dgamma=None, dbeta=None,
-                    beta=0.0, want_dbeta=True):
+def stem_conv_wgrad_item(xp, g, w_stem, hw, scale=None, mean=None, invstd=None, dw=None, dgamma=None, dbeta=None,
+                         beta=0.0, want_dbeta=True):
     H, W = hw
     N = xp.shape[0]
     Cout = w_stem.shape[0]
@@ -260,12 +312,15 @@ def stem_conv_wgrad(xp, g, w_stem, hw, scale=None, mean=None, invstd=None, dw=No
         dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
     for t, n in ((scale, "scale"), (mean, "mean"), (invstd, "invstd"), (dgamma, "dgamma"), (dbeta, "dbeta")):
         _chk_vec(t, n, Cout)
-    lib = _lib.load()
-    nbytes = lib.tdn_stem_conv_wgrad_workspace(N, H, W, Cout)
-    ws = _workspace(nbytes, dev)
-    _lib.check(lib.tdn_stem_conv_wgrad(_ptr(xp), _ptr(g), _ptr(w_stem), _ptr(scale), _ptr(mean), _ptr(invstd),
-                                       _ptr(dw), _ptr(dgamma), _ptr(dbeta), float(beta), N, H, W, Cout, _ptr(ws),
-                                       ws.numel(), dtype_code(xp.dtype), _lib.stream_ptr()), "tdn_stem_conv_wgrad")
+    it = wgrad_item(WGRAD_STEM, xp, g, w_stem, scale, mean, invstd, dw, dgamma, dbeta, beta, N, H, W, 3, Cout, 7, 2, 3)
+    return it, dw, dgamma, dbeta
+
+
+def stem_conv_wgrad(xp, g, w_stem, hw, scale=None, mean=None, invstd=None, dw=None, dgamma=None, dbeta=None,
+                    beta=0.0, want_dbeta=True):
+    it, dw, dgamma, dbeta = stem_conv_wgrad_item(xp, g, w_stem, hw, scale, mean, invstd, dw, dgamma, dbeta, beta,
+                                                 want_dbeta)
+    wgrad_group([it], xp.dtype, g.device)
     return dw, dgamma, dbeta
 
 
@@ -655,9 +710,8 @@ def gconv2d_dgrad(g, w_dgrad, groups, in_hw, k, stride, pad, addend=None, addend
     return dx
 
 
-def gconv2d_wgrad(x, g, w_fwd, groups, k, stride, pad, scale=None, mean=None, invstd=None, dw=None, dgamma=None,
-                  dbeta=None, beta=0.0, want_dbeta=True):
-    """dw fp32 [C,k,k,C/groups] (+ BN affine grads like conv2d_wgrad)."""
+def gconv2d_wgrad_item(x, g, w_fwd, groups, k, stride, pad, scale=None, mean=None, invstd=None, dw=None, dgamma=None,
+                       dbeta=None, beta=0.0, want_dbeta=True):
     _chk_act(x, "x")
     _chk_act(g, "g", None, x.dtype)
     N, H, W, C = x.shape
@@ -677,13 +731,17 @@ def gconv2d_wgrad(x, g, w_fwd, groups, k, stride, pad, scale=None, mean=None, in
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
     for t, n in ((scale, "scale"), (mean, "mean"), (invstd, "invstd"), (dgamma, "dgamma"), (dbeta, "dbeta")):
         _chk_vec(t, n, C)
-    lib = _lib.load()
-    nbytes = lib.tdn_gconv2d_wgrad_workspace(N, H, W, C, int(groups), k, stride, pad)
-    ws = _workspace(nbytes, dev)
-    _lib.check(lib.tdn_gconv2d_wgrad(_ptr(x), _ptr(g), _ptr(w_fwd), _ptr(scale), _ptr(mean), _ptr(invstd), _ptr(dw),
-                                     _ptr(dgamma), _ptr(dbeta), float(beta), N, H, W, C, int(groups), k, stride, pad,
-                                     _ptr(ws), ws.numel(), dtype_code(x.dtype), _lib.stream_ptr()),
-               "tdn_gconv2d_wgrad")
+    it = wgrad_item(WGRAD_GCONV, x, g, w_fwd, scale, mean, invstd, dw, dgamma, dbeta, beta, N, H, W, C, C, k, stride,
+                    pad, int(groups))
+    return it, dw, dgamma, dbeta
+
+
+def gconv2d_wgrad(x, g, w_fwd, groups, k, stride, pad, scale=None, mean=None, invstd=None, dw=None, dgamma=None,
+                  dbeta=None, beta=0.0, want_dbeta=True):
+    """dw fp32 [C,k,k,C/groups] (+ BN affine grads like conv2d_wgrad)."""
+    it, dw, dgamma, dbeta = gconv2d_wgrad_item(x, g, w_fwd, groups, k, stride, pad, scale, mean, invstd, dw, dgamma,
+                                               dbeta, beta, want_dbeta)
+    wgrad_group([it], x.dtype, x.device)
     return dw, dgamma, dbeta
 
 
