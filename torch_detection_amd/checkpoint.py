@@ -13,35 +13,21 @@ import torch
 
 
 def load_state_dict(module, state_dict, strict=False, logger=None):
-    """Copy by key name, tolerating missing / unexpected keys unless ``strict`` (checkpoint.py:11-64)."""
-    unexpected_keys = []
-    own_state = module.state_dict()
-    for name, param in state_dict.items():
-        if name not in own_state:
-            unexpected_keys.append(name)
-            continue
-        if isinstance(param, torch.nn.Parameter):
-            param = param.data
-        try:
-            own_state[name].copy_(param)
-        except Exception:
-            raise RuntimeError('While copying the parameter named {}, whose dimensions in the model are {} and '
-                               'whose dimensions in the checkpoint are {}.'.format(
-                                   name, own_state[name].size(), param.size()))
-    missing_keys = set(own_state.keys()) - set(state_dict.keys())
-    err_msg = []
-    if unexpected_keys:
-        err_msg.append('unexpected key in source state_dict: {}\n'.format(', '.join(unexpected_keys)))
-    if missing_keys:
-        err_msg.append('missing keys in source state_dict: {}\n'.format(', '.join(sorted(missing_keys))))
-    err_msg = '\n'.join(err_msg)
-    if err_msg:
-        if strict:
-            raise RuntimeError(err_msg)
-        elif logger is not None:
-            logger.warning(err_msg)
-        else:
-            print(err_msg)
+    """Non-strict load by key name (the behaviour of checkpoint.py:11-64), built on PyTorch's own loader: tensors whose
+    shapes disagree raise ``RuntimeError`` (``nn.Module.load_state_dict`` reports them even when not strict); keys
+    only one side has are reported — raised with ``strict``, else logged / printed."""
+    report = module.load_state_dict(state_dict, strict=False)
+    lines = []
+    if report.unexpected_keys:
+        lines.append('unexpected key in source state_dict: ' + ', '.join(report.unexpected_keys))
+    if report.missing_keys:
+        lines.append('missing keys in source state_dict: ' + ', '.join(sorted(report.missing_keys)))
+    if not lines:
+        return
+    text = '\n'.join(lines)
+    if strict:
+        raise RuntimeError(text)
+    (logger.warning if logger is not None else print)(text)
 
 
 def load_checkpoint(model, filename, map_location=None, strict=False, logger=None):

@@ -229,15 +229,17 @@ def _gn_store(u):
     return st
 
 
-def unit_fwd(u, x, addend=None, addend_mode=ADD_NONE, relu=None):
+def unit_fwd(u, x, addend=None, addend_mode=ADD_NONE, relu=None, out=None):
     relu = u.relu if relu is None else relu
     if relu and u.act6:
         relu = 2                 # nn.ReLU6: the conv epilogue clamps at 6 as well
+    if out is not None and (u.gn or u.bnt or u.groups > 1):
+        raise NotImplementedError('caller-provided outputs: plain conv (+ folded BN) units only')
     if not (u.gn or u.bnt):
         if u.groups > 1:
             return ops.gconv2d_fwd(x, u.w_fwd, u.groups, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode,
                                    relu)
-        return ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode, relu)
+        return ops.conv2d_fwd(x, u.w_fwd, u.k, u.stride, u.pad, u.scale, u.shift, addend, addend_mode, relu, out=out)
     if u.groups > 1:
         z = ops.gconv2d_fwd(x, u.w_fwd, u.groups, u.k, u.stride, u.pad, None, u.shift)
     else:
@@ -692,23 +694,108 @@ class SeqNet(object):
         return ps
 
 
-def _block_fwd(x, b):
+def _block_fwd(x, b, bufs=None):
+    """One residual block.  ``bufs`` = caller-provided (h1, h2, out, res) outputs — one image's slices of batch
+    tensors when the images of a batch run as separate chains (ImageSplit); everything then stays on the routed
+    stream (no branch stream for the downsample conv)."""
     res, br = x, None
+    o1 = o2 = o3 = ores = None
+    if bufs is not None:
+        o1, o2, o3, ores = bufs
     if b.ud is not None:
-        with branch(x.device, b.ud, (x,)) as br:    # the downsample conv runs beside conv1 (-> conv2)
-            res = unit_fwd(b.ud, x, relu=False)
+        if bufs is not None:
+            res = unit_fwd(b.ud, x, relu=False, out=ores)
+        else:
+            with branch(x.device, b.ud, (x,)) as br:    # the downsample conv runs beside conv1 (-> conv2)
+                res = unit_fwd(b.ud, x, relu=False)
     if b.kind == 'bottleneck':
-        h1 = unit_fwd(b.u1, x, relu=True)
-        h2 = unit_fwd(b.u2, h1, relu=True)
+        h1 = unit_fwd(b.u1, x, relu=True, out=o1)
+        h2 = unit_fwd(b.u2, h1, relu=True, out=o2)
         if br is not None:
             br.join()
-        out = unit_fwd(b.u3, h2, res, ADD_SAME, True)
+        out = unit_fwd(b.u3, h2, res, ADD_SAME, True, out=o3)
         return out, (x, h1, h2, out)
-    h1 = unit_fwd(b.u1, x, relu=True)
+    h1 = unit_fwd(b.u1, x, relu=True, out=o1)
     if br is not None:
         br.join()
-    out = unit_fwd(b.u2, h1, res, ADD_SAME, True)
+    out = unit_fwd(b.u2, h1, res, ADD_SAME, True, out=o3)
     return out, (x, h1, None, out)
+
+
+# Small-M stages (layer3 / layer4 at the BASELINE batch of 2: 8,400 and 2,100 pixels) cannot fill 256 CUs from one
+# launch — 132 ... 528 workgroups with short K loops, each launch paying its own ramp, tail and dependency gap.  The
+# images of a batch are independent (eval-mode BN), so from the first block whose batch has at most TDN_IMG_SPLIT_M
+# pixels on, the forward chain runs once per image, each chain on a stream of its own: the launches of one image fill
+# the gaps of the other's.  Outputs are the image slices of ordinary batch tensors (backward is unchanged).
+_split_streams = {}
+
+
+def _img_split_m():
+    return int(os.environ.get('TDN_IMG_SPLIT_M', '20000'))
+
+
+def _splittable(b):
+    return all(not (u.gn or u.bnt) and u.groups == 1 for u in b.units())
+
+
+def _blocks_fwd_split(blocks, cur):
+    """Forward of ``blocks`` on batch ``cur`` (N >= 2) as N per-image chains on N streams; returns (out, saved)."""
+    dev = cur.device
+    N = cur.shape[0]
+    key = (dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
+    ways = max(2, min(N, int(os.environ.get('TDN_IMG_SPLIT_WAYS', '4'))))
+    cuts = [N * i // ways for i in range(ways + 1)]      # contiguous image ranges, one chain each
+    pool = _split_streams.get(key)
+    if pool is None or len(pool) < ways:
+        pool = [torch.cuda.Stream(device=dev) for _ in range(ways)]
+        _split_streams[key] = pool
+    # batch tensors of every block, allocated on the current stream
+    bufs, x = [], cur
+    for b in blocks:
+        H, W = x.shape[1], x.shape[2]
+
+        def new(hh, ww, c):
+            return torch.empty(N, hh, ww, c, dtype=x.dtype, device=dev)
+        if b.kind == 'bottleneck':
+            h1 = new(ops.conv_out_size(H, b.u1.k, b.u1.stride, b.u1.pad),
+                     ops.conv_out_size(W, b.u1.k, b.u1.stride, b.u1.pad), b.u1.Cout)
+            h2 = new(ops.conv_out_size(h1.shape[1], b.u2.k, b.u2.stride, b.u2.pad),
+                     ops.conv_out_size(h1.shape[2], b.u2.k, b.u2.stride, b.u2.pad), b.u2.Cout)
+            out = new(h2.shape[1], h2.shape[2], b.u3.Cout)
+        else:
+            h1 = new(ops.conv_out_size(H, b.u1.k, b.u1.stride, b.u1.pad),
+                     ops.conv_out_size(W, b.u1.k, b.u1.stride, b.u1.pad), b.u1.Cout)
+            h2 = None
+            out = new(h1.shape[1], h1.shape[2], b.u2.Cout)
+        res = new(out.shape[1], out.shape[2], out.shape[3]) if b.ud is not None else None
+        bufs.append((h1, h2, out, res))
+        x = out
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    done = []
+    for i in range(ways):
+        st = pool[i]
+        st.wait_event(ev)
+        prev = _lib.set_stream_override(st.cuda_stream)
+        a, e_ = cuts[i], cuts[i + 1]
+        try:
+            xi = cur[a:e_]
+            for b, (h1, h2, out, res) in zip(blocks, bufs):
+                xi, _ = _block_fwd(xi, b, (h1[a:e_], h2[a:e_] if h2 is not None else None, out[a:e_],
+                                           res[a:e_] if res is not None else None))
+        finally:
+            _lib.set_stream_override(prev)
+        e = torch.cuda.Event()
+        e.record(st)
+        done.append(e)
+    main = torch.cuda.current_stream(dev)
+    for e in done:
+        main.wait_event(e)
+    saved, x = [], cur
+    for (h1, h2, out, res) in bufs:
+        saved.append((x, h1, h2, out))
+        x = out
+    return x, saved
 
 
 def _block_bwd(b, saved, g, extra, mask_src, need_dx, wq=None):
@@ -786,11 +873,28 @@ class SeqNetFunction(torch.autograd.Function):
         else:
             cur = ops.to_nhwc_bf16(x, net.dtype)
         saved, outs = [], []
-        for bi, b in enumerate(net.blocks):
+        nb = len(net.blocks)
+        bi = 0
+        split_m = _img_split_m()
+        while bi < nb:
+            b = net.blocks[bi]
+            # pixels of this block's output batch (stride on conv2 / conv1: the block works at the reduced size)
+            m_out = cur.shape[0] * -(-cur.shape[1] // b.stride) * -(-cur.shape[2] // b.stride)
+            if split_m > 0 and cur.shape[0] >= 2 and m_out <= split_m and \
+                    all(_splittable(bb) for bb in net.blocks[bi:]):
+                join_branches(cur.device)
+                cur, svs = _blocks_fwd_split(net.blocks[bi:], cur)
+                for j, sv in enumerate(svs):
+                    saved.append(sv)
+                    if bi + j in net.out_blocks:
+                        outs.append(sv[3])
+                bi = nb
+                break
             cur, sv = _block_fwd(cur, b)
             saved.append(sv)
             if bi in net.out_blocks:
                 outs.append(cur)
+            bi += 1
         if not net.blocks:
             outs.append(cur)
         join_branches(cur.device)

@@ -124,8 +124,16 @@ def pack_stem_weight(w, dtype=BF16):
     return out
 
 
+def _out_buffer(out, shape, dtype, name):
+    """Caller-provided output (e.g. one image's slice of a batch tensor): must be exactly what would be allocated."""
+    if tuple(out.shape) != tuple(shape) or out.dtype != dtype or not out.is_cuda or not out.is_contiguous():
+        raise ValueError("%s: out must be a contiguous CUDA %s tensor of shape %s, got %s %s" %
+                         (name, dtype, tuple(shape), out.dtype, tuple(out.shape)))
+    return out
+
+
 def conv2d_fwd(x, w_fwd, k, stride, pad, scale=None, shift=None, addend=None, addend_mode=ADD_NONE, relu=False,
-               out_f32=False):
+               out_f32=False, out=None):
     _chk_act(x, "x")
     N, H, W, Cin = x.shape
     Cout = w_fwd.shape[0]
@@ -133,7 +141,9 @@ def conv2d_fwd(x, w_fwd, k, stride, pad, scale=None, shift=None, addend=None, ad
         raise ValueError("w_fwd must be %s [Cout,k,k,Cin] contiguous, got %s %s" %
                          (x.dtype, w_fwd.dtype, tuple(w_fwd.shape)))
     Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
-    y = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    odt = torch.float32 if out_f32 else x.dtype
+    y = torch.empty(N, Ho, Wo, Cout, dtype=odt, device=x.device) if out is None else \
+        _out_buffer(out, (N, Ho, Wo, Cout), odt, "conv2d_fwd")
     ep = make_epilogue(Cout, Ho, Wo, scale, shift, addend, addend_mode, relu, None, N, out_f32, x.dtype)
     _lib.check(_lib.load().tdn_conv2d_fwd(_ptr(x), _ptr(w_fwd), _ptr(y), N, H, W, Cin, Cout, k, stride, pad,
                                           ctypes.byref(ep), dtype_code(x.dtype), _lib.stream_ptr()), "tdn_conv2d_fwd")
@@ -141,7 +151,7 @@ def conv2d_fwd(x, w_fwd, k, stride, pad, scale=None, shift=None, addend=None, ad
 
 
 def conv2d_dgrad(g, w_dgrad, in_hw, k, stride, pad, addend=None, addend_mode=ADD_NONE, mask_src=None,
-                 out_f32=False):
+                 out_f32=False, out=None):
     """dx (N,H,W,Cin) from g (N,Ho,Wo,Cout); epilogue: + addend, then ReLU mask by mask_src > 0."""
     _chk_act(g, "g")
     N, Ho, Wo, Cout = g.shape
@@ -152,7 +162,9 @@ def conv2d_dgrad(g, w_dgrad, in_hw, k, stride, pad, addend=None, addend_mode=ADD
                          (g.dtype, w_dgrad.dtype, tuple(w_dgrad.shape)))
     if (Ho, Wo) != (conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)):
         raise RuntimeError("dgrad: g spatial size %s inconsistent with input %s" % ((Ho, Wo), (H, W)))
-    dx = torch.empty(N, H, W, Cin, dtype=torch.float32 if out_f32 else g.dtype, device=g.device)
+    odt = torch.float32 if out_f32 else g.dtype
+    dx = torch.empty(N, H, W, Cin, dtype=odt, device=g.device) if out is None else \
+        _out_buffer(out, (N, H, W, Cin), odt, "conv2d_dgrad")
     ep = make_epilogue(Cin, H, W, None, None, addend, addend_mode, False, mask_src, N, out_f32, g.dtype)
     _lib.check(_lib.load().tdn_conv2d_dgrad(_ptr(g), _ptr(w_dgrad), _ptr(dx), N, H, W, Cin, Cout, k, stride, pad,
                                             ctypes.byref(ep), dtype_code(g.dtype), _lib.stream_ptr()), "tdn_conv2d_dgrad")
