@@ -374,6 +374,86 @@ def test_graphed_step_matches_eager(T):
     assert all(torch.equal(p.grad, g) for p, g in zip(params, got_g))
 
 
+def _small_net(T):
+    m = T.ResNet(18).cuda().train()
+    m.init_weights()
+    neck = T.FPN([64, 128, 256, 512], 256, 5).cuda()
+    neck.init_weights()
+    x = det_tensor((2, 3, 64, 96), 9, -1, 1).cuda()
+    return m, neck, x, list(m.parameters()) + list(neck.parameters())
+
+
+def test_graphed_step_refuses_live_outside_graph(T):
+    """An ordinary grad-mode forward whose outputs are still alive keeps the parameters' AccumulateGrad nodes bound
+    to the default stream; capturing then used to crash inside capture_end.  GraphedStep(params=...) must detect
+    it, not capture, and run eagerly with the right results; once the outputs are gone the capture works."""
+    m, neck, x, params = _small_net(T)
+    outs = neck(m(x))                     # grad mode, outputs held
+    cots = [det_tensor(tuple(o.shape), 20 + i, -1, 1).cuda().to(o.dtype) for i, o in enumerate(outs)]
+
+    def step():
+        for p in params:
+            p.grad = None
+        torch.autograd.backward(neck(m(x)), cots)
+
+    gs = T.GraphedStep(step, params=params, verbose=False)
+    assert not gs.captured and "autograd graph" in str(gs.error)
+    gs()                                  # eager fallback
+    torch.cuda.synchronize()
+    eager = [p.grad.clone() for p in params]
+    del outs
+    gs2 = T.GraphedStep(step, params=params)
+    assert gs2.captured, gs2.error
+    gs2()
+    torch.cuda.synchronize()
+    assert all(torch.equal(p.grad, g) for p, g in zip(params, eager))
+
+
+@pytest.mark.parametrize("how", ["inplace", "data_copy"])
+def test_graph_replay_sees_weight_update(T, how):
+    """replay -> SGD update OUTSIDE the captured callable -> replay must equal the eager step on the updated weights:
+    the pack / BN-fold kernels are part of the graph (repack=True) and read the live fp32 parameters."""
+    m, neck, x, params = _small_net(T)
+    with torch.no_grad():
+        outs = neck(m(x))
+    cots = [det_tensor(tuple(o.shape), 20 + i, -1, 1).cuda().to(o.dtype) for i, o in enumerate(outs)]
+    del outs
+    held = {}
+
+    def step():
+        for p in params:
+            p.grad = None
+        o = neck(m(x))
+        torch.autograd.backward(o, cots)
+        held["o"] = o
+
+    gs = T.GraphedStep(step, params=params)
+    assert gs.captured, gs.error
+    gs()
+    torch.cuda.synchronize()
+    before = [t.clone() for t in held["o"]]
+    with torch.no_grad():                 # the update an optimizer would make, outside the graph
+        for i, p in enumerate(params):
+            upd = p * (1.0 + 0.01 * ((i % 3) - 1)) + 0.01
+            if how == "inplace":
+                p.copy_(upd)
+            else:
+                p.data.copy_(upd)         # does not bump p._version: only the in-graph repack can see it
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.add_(0.05)
+    gs()
+    torch.cuda.synchronize()
+    got_o = [t.clone() for t in held["o"]]
+    got_g = [p.grad.clone() for p in params]
+    assert not all(torch.equal(a, b) for a, b in zip(got_o, before))
+    T.invalidate_packed(m, neck)          # eager reference: needed for the data_copy case (no version bump)
+    step()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(held["o"], got_o))
+    assert all(torch.equal(p.grad, g) for p, g in zip(params, got_g))
+
+
 @pytest.mark.parametrize("depth", [18, 50])
 def test_branch_streams_change_nothing(T, depth, monkeypatch):
     """functional.branch moves independent launches (downsample conv / dgrad, coarse FPN output convs, lateral dgrads)

@@ -89,6 +89,8 @@ class ConvUnit(object):
                                           '(channels: a power of two in 64..2048)' % (G, C, bn.affine))
         self.key = None
         self.w_fwd = self.w_dgrad = self.scale = self.shift = self.invstd = self.mean = None
+        self._fold = self._shift_b = self._mean_b = None   # persistent buffers behind scale / shift / invstd / mean
+        self._layout = None
         self.sink = None      # optional (dw, d_affine0, d_affine1) views owned by a gradient bucket (dp.py)
         self.on_grads = None  # optional callback(unit) fired when this unit's grads have been enqueued
 
@@ -113,7 +115,13 @@ class ConvUnit(object):
         return tuple(key)
 
     def refresh(self):
-        """(Re)pack weights / fold BN if any source tensor changed since the last call."""
+        """(Re)pack weights / fold BN if any source tensor changed since the last call.
+
+        While a hipGraph is being captured (``graph.GraphedStep``, or a caller's own ``torch.cuda.graph``) and
+        ``REPACK_IN_CAPTURE`` is set, the pack / fold kernels are ALWAYS enqueued, writing into the unit's existing
+        buffers: they become graph nodes that read the live fp32 parameters, so a replay after an optimizer update
+        computes with the updated weights.  Otherwise the version key decides; updates that bypass the version
+        counter (``p.data.copy_``, raw-pointer kernels) need ``invalidate_packed(module)``."""
         self.bnt = self.bn is not None and not self.gn and self.bn.training
         if self.bnt and (self.bn.momentum is None or not self.bn.affine):
             raise NotImplementedError('training-mode BatchNorm2d needs affine=True and a numeric momentum on the HIP '
@@ -123,8 +131,15 @@ class ConvUnit(object):
             raise RuntimeError('torch_detection_amd modules run on the MI355X HIP path only: move the module to '
                                'a CUDA/HIP device (no CPU fallback)')
         key = self._version_key()
-        if key == self.key:
+        capturing = REPACK_IN_CAPTURE and torch.cuda.is_current_stream_capturing()
+        if key == self.key and not capturing:
             return self
+        # same sources as last time (only their contents may differ): overwrite the buffers in place — during capture
+        # that is what makes the graph self-contained, and addresses other captured nodes hold stay valid
+        layout = (w.device, self.dtype, tuple(w.shape), self.gn, self.bnt, self.bn is not None,
+                  self.conv.bias is not None)
+        reuse = self.w_fwd is not None and layout == self._layout
+        self._layout = layout
         with torch.no_grad():
             if w.dtype != torch.float32:
                 raise NotImplementedError('parameters must be float32 (bf16 operands are derived on the fly)')
@@ -132,25 +147,54 @@ class ConvUnit(object):
                 self.scale = self.invstd = self.mean = None   # gamma / beta are read at launch time
                 self.shift = self.conv.bias.detach() if self.conv.bias is not None else None   # z = conv + bias
             elif self.bn is not None:
+                fold = self._fold if (reuse and self._fold is not None) else None
                 self.scale, self.shift, self.invstd = ops.bn_fold(self.bn.weight, self.bn.bias, self.bn.running_mean,
-                                                                  self.bn.running_var, self.bn.eps)
+                                                                  self.bn.running_var, self.bn.eps, out=fold)
+                self._fold = self.scale._base if self.scale._base is not None else None
                 self.mean = self.bn.running_mean
                 if self.conv.bias is not None:
                     # bn(conv + b) = scale * conv + (shift + scale * b);  z - mean = conv - (mean - b)
-                    self.shift = self.shift + self.scale * self.conv.bias.detach()
-                    self.mean = self.bn.running_mean - self.conv.bias.detach()
+                    b = self.conv.bias.detach()
+                    if reuse and self._shift_b is not None:
+                        torch.addcmul(self.shift, self.scale, b, out=self._shift_b)
+                        torch.sub(self.bn.running_mean, b, out=self._mean_b)
+                    else:
+                        self._shift_b = self.shift + self.scale * b
+                        self._mean_b = self.bn.running_mean - b
+                    self.shift, self.mean = self._shift_b, self._mean_b
             else:
                 self.scale = self.invstd = self.mean = None
                 self.shift = self.conv.bias.detach() if self.conv.bias is not None else None
             if self.is_stem:
-                self.w_fwd = ops.pack_stem_weight(w.detach().contiguous(), self.dtype)
+                self.w_fwd = ops.pack_stem_weight(w.detach().contiguous(), self.dtype,
+                                                  out=self.w_fwd if reuse else None)
                 self.w_dgrad = None
             elif self.groups > 1:
-                self.w_fwd, self.w_dgrad = ops.pack_gconv_weight(w, self.groups, self.scale, True, self.dtype)
+                self.w_fwd, self.w_dgrad = ops.pack_gconv_weight(
+                    w, self.groups, self.scale, True, self.dtype,
+                    out=(self.w_fwd, self.w_dgrad) if reuse and self.w_dgrad is not None else None)
             else:
-                self.w_fwd, self.w_dgrad = ops.pack_conv_weight(w, self.scale, True, self.dtype)
+                self.w_fwd, self.w_dgrad = ops.pack_conv_weight(
+                    w, self.scale, True, self.dtype,
+                    out=(self.w_fwd, self.w_dgrad) if reuse and self.w_dgrad is not None else None)
         self.key = key
         return self
+
+
+# Whether units re-run their pack / fold kernels inside a hipGraph capture (see ConvUnit.refresh).  GraphedStep sets
+# it for the duration of its capture (``repack=True``, the default).
+REPACK_IN_CAPTURE = True
+
+
+def invalidate_packed(*modules):
+    """Forget the packed operands / folded BN constants of every conv unit under ``modules``: the next forward
+    re-derives them from the fp32 parameters.  Needed after parameter or running-statistics updates that do not bump
+    the tensors' version counters (``p.data.copy_()``, ``p.data.mul_()``, kernels writing through raw pointers);
+    ordinary in-place updates under ``torch.no_grad()`` (what optimizers do) are picked up automatically."""
+    for m in modules:
+        for sub in m.modules():
+            for u in sub.__dict__.get('_hip_units', {}).values():
+                u.key = None
 
 
 class StagedImages(object):
@@ -731,7 +775,7 @@ _split_streams = {}
 
 
 def _img_split_m():
-    return int(os.environ.get('TDN_IMG_SPLIT_M', '20000'))
+    return int(os.environ.get('TDN_IMG_SPLIT_M', '300000'))
 
 
 def _splittable(b):
@@ -772,25 +816,25 @@ def _blocks_fwd_split(blocks, cur):
         x = out
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    done = []
     for i in range(ways):
-        st = pool[i]
-        st.wait_event(ev)
-        prev = _lib.set_stream_override(st.cuda_stream)
-        a, e_ = cuts[i], cuts[i + 1]
-        try:
-            xi = cur[a:e_]
-            for b, (h1, h2, out, res) in zip(blocks, bufs):
-                xi, _ = _block_fwd(xi, b, (h1[a:e_], h2[a:e_] if h2 is not None else None, out[a:e_],
-                                           res[a:e_] if res is not None else None))
-        finally:
-            _lib.set_stream_override(prev)
-        e = torch.cuda.Event()
-        e.record(st)
-        done.append(e)
+        pool[i].wait_event(ev)
+    # Launch order: block by block, alternating between the chains.  A captured hipGraph is replayed by the host in
+    # capture order, node by node (rocprofv3 timeline: with one chain captured after the other, the second chain's
+    # first kernel was submitted only when the first chain had almost run to its end) — so the chains are interleaved
+    # here and reach the GPU side by side.
+    xs = [cur[cuts[i]:cuts[i + 1]] for i in range(ways)]
+    for b, (h1, h2, out, res) in zip(blocks, bufs):
+        for i in range(ways):
+            a, e_ = cuts[i], cuts[i + 1]
+            prev = _lib.set_stream_override(pool[i].cuda_stream)
+            try:
+                xs[i], _ = _block_fwd(xs[i], b, (h1[a:e_], h2[a:e_] if h2 is not None else None, out[a:e_],
+                                                 res[a:e_] if res is not None else None))
+            finally:
+                _lib.set_stream_override(prev)
     main = torch.cuda.current_stream(dev)
-    for e in done:
-        main.wait_event(e)
+    for i in range(ways):
+        main.wait_stream(pool[i])
     saved, x = [], cur
     for (h1, h2, out, res) in bufs:
         saved.append((x, h1, h2, out))

@@ -1,38 +1,100 @@
 """hipGraph capture of a whole training / inference step.
 
 The HIP path issues ~250 small launches per ResNet-50-FPN step; through Python that is ≈7 ms of host time for a
-≈5.3 ms GPU step, so an eager loop is host-bound.  All shapes of the hot path are static (padded batches), which is
+≈4.5 ms GPU step, so an eager loop is host-bound.  All shapes of the hot path are static (padded batches), which is
 exactly what a hipGraph wants: capture the step once — forward, backward, the weight-gradient kernels on their side
 streams and, under data parallelism, the bucketed RCCL all-reduces on the comm stream — and replay it with one launch.
 
-    step = GraphedStep(lambda: run_one_step())       # run_one_step reads / writes fixed tensors
+    step = GraphedStep(lambda: run_one_step(), params=model.parameters())   # run_one_step reads / writes fixed tensors
     step()                                           # replays; falls back to eager calls if capture was refused
 
 Rules (the usual CUDA-graph ones): the callable must use the same tensors every time (copy new data INTO them),
 must not synchronise with the host, and parameter gradients must either be views of a persistent buffer
-(``dp.attach_reducer``) or be read before the next replay overwrites them.  One more, specific to autograd: no
-autograd graph of these parameters built on the DEFAULT stream may still be alive when the step is captured (probe
-output shapes under ``torch.no_grad()``): its AccumulateGrad nodes would make the captured backward synchronise with
-the default stream, which a capture cannot contain — hipStreamEndCapture crashes on it.
+(``dp.attach_reducer``) or be read before the next replay overwrites them.
+
+Weights.  With ``repack=True`` (default) every conv unit re-runs its weight-pack / BN-fold kernels inside the capture
+(``functional.ConvUnit.refresh``), so the graph reads the live fp32 parameters and running statistics: an optimizer
+step between replays — inside or outside the captured callable — is picked up.  ``repack=False`` freezes the packed
+16-bit operands at capture time (valid only while the weights do not change: inference, or a forward+backward
+benchmark with static weights); ≈ 0.5 ms of pack / fold launches per ResNet-50-FPN step are then not part of the graph.
+
+One rule is specific to autograd: no autograd graph of these parameters that was built OUTSIDE this object may still be
+alive when the step is captured (e.g. the outputs of an ordinary forward pass kept in a variable).  Such a graph keeps
+the parameters' AccumulateGrad nodes alive, and those are bound to the stream they were created on; the captured
+backward would have to synchronise with that stream, which is not part of the capture — hipStreamEndCapture then
+fails (observed as a crash inside ``capture_end``).  ``GraphedStep`` checks for it when it is given ``params`` and
+falls back to eager execution with an explanatory error instead of attempting the capture.
+
+Under ``torch.distributed`` the process group's watchdog thread polls the events of collectives that are still
+pending.  The capture runs with ``capture_error_mode="thread_local"``: only the capturing thread's calls are policed,
+so an event query from the watchdog thread during the capture window is legal (in the default "global" mode any
+thread's query invalidates the capture — the abort seen once in four runs).  In addition the warm-up's collectives are
+drained deterministically first (``ProcessGroup._wait_for_pending_works``), so the watchdog has nothing left to query.
 """
 import sys
-import time
 
 import torch
 
 
+def _accumulator(p):
+    """The AccumulateGrad node of leaf ``p`` (created if none is alive)."""
+    with torch.enable_grad():
+        return p.expand_as(p).grad_fn.next_functions[0][0]
+
+
+def params_with_live_graph(params):
+    """Parameters whose AccumulateGrad node is referenced by someone else — i.e. an autograd graph using them is still
+    alive.  A marker is left in the node's ``metadata`` dict (which lives as long as the node); if, after dropping our
+    own reference, the node handed out next still carries the marker, it is the same node: something else owns it."""
+    held = []
+    token = object()
+    for p in params:
+        if not (isinstance(p, torch.Tensor) and p.requires_grad and p.is_leaf):
+            continue
+        node = _accumulator(p)
+        node.metadata['tdn_graph_probe'] = token
+        del node
+        again = _accumulator(p)
+        if again.metadata.get('tdn_graph_probe') is token:
+            held.append(p)
+            again.metadata.pop('tdn_graph_probe', None)
+        del again
+    return held
+
+
+def _drain_process_group():
+    """Wait until the NCCL/RCCL watchdog has retired every pending collective (no timing involved)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    torch.cuda.synchronize()
+    try:
+        dist.distributed_c10d._get_default_group()._wait_for_pending_works()
+    except (AttributeError, RuntimeError):
+        pass   # binding absent (older torch) or backend without a watchdog: thread_local capture still covers it
+
+
 class GraphedStep(object):
     """Captures ``fn`` (after ``warmup`` eager calls on a side stream) and replays it.  ``captured`` tells whether the
-    graph exists; if capture raised, the error is printed once and every call runs ``fn`` eagerly."""
+    graph exists; if capture was refused or raised, the error is kept in ``error``, printed once, and every call runs
+    ``fn`` eagerly.  ``params``: the parameters ``fn`` differentiates (checked for live outside autograd graphs, see the
+    module docstring).  ``repack``: see "Weights" above."""
 
-    def __init__(self, fn, warmup=3, verbose=True, settle=None):
+    def __init__(self, fn, warmup=3, verbose=True, params=None, repack=True):
+        from . import functional as HF
         self.fn = fn
         self.graph = None
         self.error = None
-        if settle is None:
-            import torch.distributed as dist
-            settle = 0.5 if (dist.is_available() and dist.is_initialized()) else 0.0
+        self.repack = bool(repack)
+        prev_repack = HF.REPACK_IN_CAPTURE
         try:
+            if params is not None:
+                held = params_with_live_graph(list(params))
+                if held:
+                    raise RuntimeError(
+                        "%d parameter(s) are referenced by an autograd graph built outside GraphedStep (outputs of an "
+                        "earlier forward pass still alive?); capturing now would tie the captured backward to that "
+                        "graph's stream. Drop those tensors or run the earlier pass under torch.no_grad()" % len(held))
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -40,23 +102,23 @@ class GraphedStep(object):
                     fn()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            if settle > 0:
-                # under torch.distributed the process group's watchdog thread polls the events of the warm-up's
-                # collectives (every ~100 ms) until it has seen them complete; an event query that lands inside the
-                # capture window is an illegal call during capture and aborts the process — let the watchdog drain
-                time.sleep(settle)
+            _drain_process_group()
             g = torch.cuda.CUDAGraph()
-            # thread_local: other threads (that watchdog, the allocator's helpers) are not policed during the capture;
-            # the launches autograd's device thread makes into the capturing streams are captured either way
+            HF.REPACK_IN_CAPTURE = self.repack
+            # thread_local: other threads (the process group's watchdog, the allocator's helpers) are not policed
+            # during the capture; the launches autograd's device thread makes into the capturing streams are captured
+            # either way
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
             self.graph = g
         except Exception as e:  # noqa: BLE001 - fall back loudly, never silently
             self.error = e
             if verbose:
-                print("torch_detection_amd.graph: hipGraph capture failed (%s: %s); running eager"
+                print("torch_detection_amd.graph: hipGraph capture not used (%s: %s); running eager"
                       % (type(e).__name__, e), file=sys.stderr)
             torch.cuda.synchronize()
+        finally:
+            HF.REPACK_IN_CAPTURE = prev_repack
 
     @property
     def captured(self):

@@ -86,26 +86,42 @@ def make_epilogue(Cout, Ho, Wo, scale=None, shift=None, addend=None, addend_mode
     return ep
 
 
-def bn_fold(gamma, beta, mean, var, eps):
-    """(scale, shift, invstd) of an eval-mode BatchNorm2d (layers.py:50-54)."""
+def bn_fold(gamma, beta, mean, var, eps, out=None):
+    """(scale, shift, invstd) of an eval-mode BatchNorm2d (layers.py:50-54).  ``out``: a (3, C) float32 buffer to
+    write into (the three results are its rows) instead of a fresh one."""
     C = gamma.numel()
     for t, n in ((gamma, "gamma"), (beta, "beta"), (mean, "running_mean"), (var, "running_var")):
         _chk_vec(t.detach(), n, C)
-    out = torch.empty(3, C, dtype=torch.float32, device=gamma.device)
+    if out is None:
+        out = torch.empty(3, C, dtype=torch.float32, device=gamma.device)
+    elif tuple(out.shape) != (3, C) or out.dtype != torch.float32 or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError("bn_fold: out must be a contiguous CUDA float32 (3, %d) tensor" % C)
     _lib.check(_lib.load().tdn_bn_fold(_ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), float(eps), C,
                                        _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _lib.stream_ptr()), "tdn_bn_fold")
     return out[0], out[1], out[2]
 
 
-def pack_conv_weight(w, scale=None, want_dgrad=True, dtype=BF16):
-    """fp32 OIHW (any strides) -> (w_fwd [O][kh][kw][I], w_dgrad [I][kh][kw][O] with scale folded), both `dtype`."""
+def _pack_out(out, shapes, dtype, name):
+    """Persistent pack buffers handed back in by the caller: must be what would have been allocated."""
+    for t, shp in zip(out, shapes):
+        if t is None or tuple(t.shape) != tuple(shp) or t.dtype != dtype or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("%s: out buffers do not match %s %s" % (name, dtype, [tuple(s) for s in shapes]))
+    return out
+
+
+def pack_conv_weight(w, scale=None, want_dgrad=True, dtype=BF16, out=None):
+    """fp32 OIHW (any strides) -> (w_fwd [O][kh][kw][I], w_dgrad [I][kh][kw][O] with scale folded), both `dtype`.
+    ``out`` = (w_fwd, w_dgrad) buffers of an earlier call to overwrite in place."""
     w = w.detach()
     if w.dtype != torch.float32 or not w.is_cuda or w.dim() != 4:
         raise ValueError("weight must be a CUDA float32 4-D tensor")
     O, I, kh, kw = w.shape
     _chk_vec(scale, "scale", O)
-    w_fwd = torch.empty(O, kh, kw, I, dtype=dtype, device=w.device)
-    w_dg = torch.empty(I, kh, kw, O, dtype=dtype, device=w.device) if want_dgrad else None
+    if out is not None:
+        w_fwd, w_dg = _pack_out(out, [(O, kh, kw, I), (I, kh, kw, O)], dtype, "pack_conv_weight")
+    else:
+        w_fwd = torch.empty(O, kh, kw, I, dtype=dtype, device=w.device)
+        w_dg = torch.empty(I, kh, kw, O, dtype=dtype, device=w.device) if want_dgrad else None
     s = w.stride()
     _lib.check(_lib.load().tdn_pack_conv_weight(_ptr(w), s[0], s[1], s[2], s[3], O, I, kh, kw, _ptr(scale),
                                                 _ptr(w_fwd), _ptr(w_dg), dtype_code(dtype), _lib.stream_ptr()),
@@ -113,12 +129,15 @@ def pack_conv_weight(w, scale=None, want_dgrad=True, dtype=BF16):
     return w_fwd, w_dg
 
 
-def pack_stem_weight(w, dtype=BF16):
+def pack_stem_weight(w, dtype=BF16, out=None):
     w = w.detach()
     if w.dtype != torch.float32 or not w.is_cuda or tuple(w.shape[1:]) != (3, 7, 7) or not w.is_contiguous():
         raise ValueError("stem weight must be a contiguous CUDA float32 [Cout,3,7,7] tensor")
     O = w.shape[0]
-    out = torch.empty(O, 7, 8, 4, dtype=dtype, device=w.device)
+    if out is not None:
+        (out,) = _pack_out((out,), [(O, 7, 8, 4)], dtype, "pack_stem_weight")
+    else:
+        out = torch.empty(O, 7, 8, 4, dtype=dtype, device=w.device)
     _lib.check(_lib.load().tdn_pack_stem_weight(_ptr(w), O, _ptr(out), dtype_code(dtype), _lib.stream_ptr()),
                "tdn_pack_stem_weight")
     return out
@@ -667,7 +686,7 @@ def gn_bwd(g, z, stats, gamma, groups, dgamma=None, dbeta=None, accumulate=False
 
 
 # ---- grouped convolution (ResNeXt) ---------------------------------------------------------------------
-def pack_gconv_weight(w, groups, scale=None, want_dgrad=True, dtype=BF16):
+def pack_gconv_weight(w, groups, scale=None, want_dgrad=True, dtype=BF16, out=None):
     """Grouped conv weight fp32 [C][C/groups][kh][kw] (any strides) -> block-diagonal operands
     (w_fwd [C][kh][kw][64], w_dgrad [C][kh][kw][64] with the BN scale folded)."""
     w = w.detach()
@@ -677,8 +696,11 @@ def pack_gconv_weight(w, groups, scale=None, want_dgrad=True, dtype=BF16):
     if cpg * groups != C:
         raise ValueError("grouped weight %s does not match %d groups" % (tuple(w.shape), groups))
     _chk_vec(scale, "scale", C)
-    w_fwd = torch.empty(C, kh, kw, 64, dtype=dtype, device=w.device)
-    w_dg = torch.empty(C, kh, kw, 64, dtype=dtype, device=w.device) if want_dgrad else None
+    if out is not None:
+        w_fwd, w_dg = _pack_out(out, [(C, kh, kw, 64), (C, kh, kw, 64)], dtype, "pack_gconv_weight")
+    else:
+        w_fwd = torch.empty(C, kh, kw, 64, dtype=dtype, device=w.device)
+        w_dg = torch.empty(C, kh, kw, 64, dtype=dtype, device=w.device) if want_dgrad else None
     s = w.stride()
     _lib.check(_lib.load().tdn_pack_gconv_weight(_ptr(w), s[0], s[1], s[2], s[3], C, int(groups), kh, kw, _ptr(scale),
                                                  _ptr(w_fwd), _ptr(w_dg), dtype_code(dtype), _lib.stream_ptr()),
