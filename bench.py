@@ -28,10 +28,24 @@ FWD_GFLOP = {50: 296.96, 101: 456.06}     # per image, SURVEY §8(d)
 FWDBWD_GFLOP = {50: 885.8, 101: 1363.1}   # 3*fwd - dgrad(conv1)
 MFMA_PEAK_TFLOPS = 2500.0          # bf16 dense, MI355X_MICROARCH.md
 DOM = dict(Cin=256, Cout=256, k=3, stride=1, H=200, W=336)   # neck.fpn_convs.0: 79.27 GFLOP / image
-# HBM bytes of ONE launch of that kernel at batch 2 from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes,
-# FETCH_SIZE doubled per MI355X_MICROARCH.md): filled in from profiles/ (None until measured)
-DOM_TRAFFIC_BYTES = 1.742e8  # 2*FETCH_SIZE(51456 KiB) + WRITE_SIZE(67200 KiB); algorithmic 1.388e8
-DOM_TRAFFIC_SOURCE = "profiles/r01_pmc_dominant_kernel.txt"
+
+
+def dominant_traffic():
+    """HBM bytes of ONE launch of the dominant kernel at batch 2 from the newest committed PMC summary
+    (profiles/rNN_pmc_dominant_kernel.txt, written by scripts/pmc_bench.sh + scripts/pmc_summarize.py: separate
+    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md).  Read from the file — never typed in
+    here — so the figure cannot outlive the kernel it was measured on; (None, None) if there is no summary."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_dominant_kernel.txt")))
+    for f in reversed(files):
+        txt = open(f).read()
+        blocks = re.split(r"\n\s*\n", txt)
+        for b in blocks:      # the first kernel entry is the tagged dominant launch
+            m = re.search(r"HBM bytes per launch: corrected ([0-9.eE+]+)", b)
+            if m and "conv_gemm_kernel" in b:
+                return float(m.group(1)), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def build_models(depth, device, seed=0):
@@ -126,7 +140,7 @@ def usable_cores():
     return max(1, min(n, cap))
 
 
-def cpu_baseline(depth, iters=2):
+def cpu_baseline(depth, iters=3):
     """The CPU oracle (restatement of the reference's PyTorch-CPU path, bit-equal to it: oracle/gen_golden.py)
     timed on this host's cores on a bounded sample: `iters` fwd+bwd passes of ONE 3x800x1344 image."""
     from golden_util import det_tensor
@@ -147,10 +161,57 @@ def cpu_baseline(depth, iters=2):
         t0 = time.perf_counter()
         O.resnet_fpn_fwd_bwd(sdb, sdf, x, depth, cots)
         times.append(time.perf_counter() - t0)
-    best = min(times[1:])
-    return {"value": round(1.0 / best, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+    timed = sorted(times[1:])
+    best, med = timed[0], timed[len(timed) // 2]
+    return {"value": round(1.0 / best, 4), "median": round(1.0 / med, 4), "unit": "images/sec", "cores": cores,
+            "kind": "port",
             "sample": "%d timed fwd+bwd passes (after 1 warm-up) of one 3x%dx%d image through oracle/torch_ref.py "
-                      "(R%d-FPN, fp32, torch CPU, %d threads); best %.2f s" % (iters, H_PAD, W_PAD, depth, cores, best)}
+                      "(R%d-FPN, fp32, torch CPU, %d threads); best %.2f s, median %.2f s" %
+                      (iters, H_PAD, W_PAD, depth, cores, best, med)}
+
+
+def box_secondary(device):
+    """BASELINE config C3 beside the headline: pairwise IoU 10k x 10k, NMS of 10k boxes (thr 0.5) and the 5-level
+    anchor pyramid (268,569 anchors) — HIP-event time per call on this process's stream, algorithmic bytes of
+    SURVEY §8(d) / time.  (rocprofv3 figures of the same calls: profiles/rNN_box_kernel_stats.csv.)"""
+    import torch_detection_amd as T
+    from torch_detection_amd import ops
+
+    def timeit(fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    g = torch.Generator().manual_seed(0)
+    N = 10000
+    wh = torch.rand(N, 2, generator=g) * 248 + 8
+    x1 = torch.rand(N, generator=g) * (W_PAD - wh[:, 0])
+    y1 = torch.rand(N, generator=g) * (H_PAD - wh[:, 1])
+    boxes = torch.stack([x1, y1, x1 + wh[:, 0], y1 + wh[:, 1]], 1).float().to(device)
+    scores = torch.rand(N, generator=g).to(device)
+    out = {}
+    t = timeit(lambda: ops.bbox_iou_pairwise(boxes, boxes), 10)
+    nb = 16 * 2 * N + 4 * N * N
+    out["iou_10k_x_10k"] = {"us": round(t * 1e6, 1), "GB_per_s": round(nb / t / 1e9, 1), "algorithmic_MB": nb / 1e6}
+    t = timeit(lambda: ops.nms(boxes, scores, 0.5), 10)
+    nb = 20 * N + 2 * 8 * N * ((N + 63) // 64) + N
+    out["nms_10k_thr0.5"] = {"us": round(t * 1e6, 1), "GB_per_s": round(nb / t / 1e9, 1), "algorithmic_MB": nb / 1e6,
+                             "note": "bound by the serial keep scan, not by bytes"}
+    ag = T.AnchorGenerator(8, [8], [0.5, 1.0, 2.0])
+    sizes = [(H_PAD // s, W_PAD // s) for s in (4, 8, 16, 32)] + [((H_PAD // 32 + 1) // 2, (W_PAD // 32 + 1) // 2)]
+    strides = [4, 8, 16, 32, 64]
+    t = timeit(lambda: T.anchor_pyramid([ag] * 5, sizes, strides, device) if hasattr(T, "anchor_pyramid") else
+               [ag.grid_anchors(fs, st, device) for fs, st in zip(sizes, strides)], 20)
+    na = sum(h * w * 3 for h, w in sizes)
+    out["anchor_pyramid_5_levels"] = {"us": round(t * 1e6, 1), "GB_per_s": round(17 * na / t / 1e9, 1),
+                                      "anchors": na, "algorithmic_MB": 17 * na / 1e6}
+    return out
 
 
 def main():
@@ -165,6 +226,7 @@ def main():
                          "(cotangents x1024: static loss scale)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the box-op and repack side measurements")
     ap.add_argument("--bucket-mb", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--force-reducer", action="store_true",
@@ -246,15 +308,32 @@ def main():
     # ---- execution mode: the whole step — forward, backward and (N > 1) the bucketed RCCL all-reduces on their
     # comm stream — captured once into a hipGraph and replayed; eager launches if capture is refused ----
     graph, mode = None, "eager"
+    repack_graph = None
     if not args.no_graph:
         from torch_detection_amd.graph import GraphedStep
-        gs = GraphedStep(step)
-        if gs.captured:
+        # headline: forward + backward with STATIC weights (the metric BASELINE.json names) — the packed 16-bit operands
+        # are derived once; config.weights_static says so and ms_per_step_with_repack (below) is the same step with
+        # the fold + pack launches of a real training step (weights change every iteration) inside the graph
+        gs = GraphedStep(step, params=params, repack=False)
+        ok = 1 if gs.captured else 0
+        if use_dist:
+            # every rank must run the same mode: a graph on some ranks and eager launches on others would still be
+            # correct (same collectives in the same order) but is a configuration nobody has measured — agree on the
+            # weakest outcome
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and ok:
+                print("rank %d: another rank could not capture; running eager everywhere" % rank, file=sys.stderr)
+                ok = 0
+        if ok:
             graph = gs
             mode = "hipGraph replay (one captured fwd+bwd step; wgrad kernels on forked side streams%s)" % (
                 "; bucketed RCCL all-reduce nodes on a comm stream inside the graph" if use_dist else "")
+            if world == 1 and not args.no_secondary:
+                rg = GraphedStep(step, params=params, repack=True)
+                repack_graph = rg if rg.captured else None
         else:
-            mode = "eager (graph capture failed)"
+            mode = "eager (graph capture failed%s)" % ("" if gs.captured else ": %s" % type(gs.error).__name__)
 
     if graph is None:
         # eager launches: run autograd's backward on this thread — the hand-off to the engine's device thread costs
@@ -294,6 +373,16 @@ def main():
                 step()
             torch.cuda.synchronize()
         timed_in = "eager steps right after the timed region (events cannot be read from a replayed graph)"
+    ms_repack = None
+    if repack_graph is not None:
+        for _ in range(2):
+            repack_graph()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            repack_graph()
+        torch.cuda.synchronize()
+        ms_repack = (time.perf_counter() - t0) / args.steps * 1e3
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -308,12 +397,20 @@ def main():
             ms, nimg, cnt = timer.summary()
             flop = 2.0 * nimg * DOM["H"] * DOM["W"] * DOM["Cout"] * DOM["Cin"] * DOM["k"] ** 2
             ach = flop / (ms * 1e-3) / 1e12
+            traffic, traffic_src = dominant_traffic()
+            import ctypes
+            from torch_detection_amd import _lib
+            plan = (ctypes.c_int32 * 16)()
+            _lib.check(_lib.load().tdn_conv2d_plan(0, nimg, DOM["H"], DOM["W"], DOM["Cin"], DOM["Cout"], DOM["k"],
+                                                   DOM["stride"], 1, plan), "tdn_conv2d_plan")
             roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": DOM_TRAFFIC_BYTES if nimg == 2 else None, "traffic_source": DOM_TRAFFIC_SOURCE,
-                    "kernel": "conv_gemm_kernel<192,256,64,2,4,2,6,1> = 3x3 256->256 conv GEMM, M=%d N=256 K=2304 "
-                              "(neck.fpn_convs.0 forward + its dgrad, 2 launches/step), %.1f GFLOP per launch" %
-                              (nimg * DOM["H"] * DOM["W"], flop / 1e9),
+                    "traffic": traffic if nimg == 2 else None, "traffic_source": traffic_src,
+                    "algorithmic_bytes": (2 * nimg * DOM["H"] * DOM["W"] * 256 + 256 * 2304) * 2,
+                    "kernel": "conv_gemm_kernel, %dx%dx%d tile (symbol tagged for the timed launches) = 3x3 256->256 "
+                              "conv GEMM, M=%d N=256 K=2304 (neck.fpn_convs.0 forward + its dgrad, 2 launches/step), "
+                              "%.1f GFLOP per launch" %
+                              (plan[3], plan[4], plan[5], nimg * DOM["H"] * DOM["W"], flop / 1e9),
                     "avg_ms": round(ms, 4), "launches_timed": cnt, "timed_in": timed_in}
         line = {
             "metric": "images/sec ResNet-50-FPN fwd+bwd 1333x800" if args.depth == 50 else
@@ -327,10 +424,17 @@ def main():
                                    (args.depth, B, ", bucketed RCCL all-reduce (sum/%d) overlapped with backward"
                                     % world if world > 1 else ""),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "execution": mode,
+                       "weights_static": True,
                        "mfma_frac_whole_step": round(mfma_frac, 4),
                        "algorithmic_gflop_per_image": FWDBWD_GFLOP[args.depth]},
             "roofline": roof,
         }
+        if ms_repack is not None:
+            # the same step with every conv's BN fold + weight pack re-run inside the graph (grouped launches), i.e.
+            # what one iteration of a training loop pays on top once an optimizer changes the weights
+            line["ms_per_step_with_repack"] = round(ms_repack, 3)
+        if world == 1 and not args.no_secondary:
+            line["secondary"] = box_secondary(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.depth)
         print(json.dumps(line), flush=True)

@@ -158,6 +158,28 @@ int tdn_wgrad_group(const tdn_wgrad_item* items, int n, void* workspace, int64_t
  * totals[4] = {gradient-kernel launches, finalize launches, workgroups, slab KiB}. */
 int tdn_wgrad_group_plan(const tdn_wgrad_item* items, int n, int dtype, int32_t* per_item, int32_t* totals);
 
+/* ---- operand preparation of many conv units in one launch -----------------------------------------------------
+ * What tdn_bn_fold + tdn_pack_conv_weight do per layer (the eval-mode BN fold of models/utils/layers.py:50-54 as the
+ * reference's default bn_eval=True makes it, resnet.py:270-276, and the 16-bit copies of nn.Conv2d.weight), for a
+ * whole list of plain convolutions (groups = 1, channels multiples of 64) at once: a training step re-derives every
+ * operand after the optimizer update, and 113 launches become ceil(n / 30).  Results are bit-identical to the
+ * per-layer calls.  gamma == NULL: no norm (scale 1, `fold` untouched).  items / n: HOST array. */
+typedef struct tdn_prep_item {
+  const float* w;            /* fp32 logical [Cout][Cin][kh][kw], element strides s_o, s_i, s_h, s_w */
+  void* w_fwd;               /* 16-bit [Cout][kh][kw][Cin] */
+  void* w_dgrad;             /* 16-bit [Cin][kh][kw][Cout] = elem(elem(w) * scale[co]); may be NULL */
+  const float* gamma;        /* BatchNorm2d weight / bias / running_mean / running_var, or all NULL */
+  const float* beta;
+  const float* mean;
+  const float* var;
+  float* fold;               /* fp32 [3][Cout]: scale, shift, invstd (written when gamma != NULL) */
+  int64_t s_o, s_i, s_h, s_w;
+  int32_t Cout, Cin, kh, kw;
+  float eps;
+  int32_t reserved;
+} tdn_prep_item;
+int tdn_prepare_group(const tdn_prep_item* items, int n, int dtype, void* stream);
+
 /* ---- grouped convolution (ResNeXt) -----------------------------------
  * conv3x3_group(..., groups=cardinality) of models/backbone/resnext.py:26-28,82-83: C channels in and out,
  * `groups` groups.  Computed in block-diagonal form: every 64-channel block of the output multiplies only the same
@@ -254,6 +276,15 @@ int tdn_nhwc_to_nchw_f32(const void* src, int N, int C, int H, int W, float* dst
  * valid[...] = x < valid_w && y < valid_h (uint8, may be NULL). */
 int tdn_anchor_grid(const float* base_anchors, int A, int featH, int featW, int stride,
                     int valid_h, int valid_w, float* anchors, uint8_t* valid, void* stream);
+
+/* The whole pyramid in one launch: `nlevels` (<= 8) levels, outputs concatenated level after level — anchors fp32
+ * [sum_l featH_l*featW_l*A_l][4], valid (may be NULL) one byte per anchor; inside a level exactly what tdn_anchor_grid
+ * writes.  levels: HOST array; base_anchors: device pointers. */
+typedef struct tdn_anchor_level {
+  const float* base_anchors;   /* device, fp32 [A][4] */
+  int32_t A, featH, featW, stride, valid_h, valid_w;
+} tdn_anchor_level;
+int tdn_anchor_pyramid(const tdn_anchor_level* levels, int nlevels, float* anchors, uint8_t* valid, void* stream);
 
 /* iou[N][M] (fp32) of inclusive-pixel xyxy boxes, '+1' convention, IEEE fp32 (no contraction). */
 int tdn_bbox_iou_pairwise(const float* a, int N, const float* b, int M, float* iou, void* stream);

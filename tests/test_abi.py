@@ -30,6 +30,34 @@ def test_epilogue_struct_layout():
     assert Epilogue.mask_src.offset == 40 and Epilogue.out_f32.offset == 48
 
 
+def test_struct_mirrors_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct of include/tdn.h as gcc lays it out == the ctypes mirrors in _lib.py."""
+    import subprocess
+    from torch_detection_amd import _lib
+    mirrors = {"tdn_epilogue": _lib.Epilogue, "tdn_wgrad_item": _lib.WgradItem, "tdn_prep_item": _lib.PrepItem}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tdn.h"', 'int main(void) {']
+    for cname, cls in mirrors.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    seen = 0
+    for ln in out:
+        if not ln:
+            continue
+        cname, fname, val = ln.split()
+        cls = mirrors[cname]
+        got = ctypes.sizeof(cls) if fname == "sizeof" else getattr(cls, fname).offset
+        assert got == int(val), (cname, fname, got, val)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in mirrors.values())
+
+
 def test_host_side_plans_and_errors():
     """tdn_conv2d_plan is host-only: GEMM decomposition of the BASELINE shapes."""
     from torch_detection_amd import _lib

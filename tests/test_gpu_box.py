@@ -48,6 +48,26 @@ def test_anchor_grid_pyramid(ops):
     assert total == 268569
 
 
+def test_anchor_pyramid_one_launch(ops):
+    """tdn_anchor_pyramid: all five levels from one launch == the per-level kernel == the C oracle, bit for bit,
+    valid flags included; an empty level in the middle is fine."""
+    import torch_detection_amd as T
+    gens = [T.AnchorGenerator(st, [8], [0.5, 1.0, 2.0]) for _, st in LEVELS]
+    sizes = [fs for fs, _ in LEVELS]
+    strides = [st for _, st in LEVELS]
+    vsizes = [(fh - 1, fw - 2) for fh, fw in sizes]
+    anchors, flags = T.anchor_pyramid(gens, sizes, strides, "cuda", vsizes)
+    assert sum(a.shape[0] for a in anchors) == 268569
+    for g, fs, st, vs, a, v in zip(gens, sizes, strides, vsizes, anchors, flags):
+        ref, vref = B.anchor_grid(B.base_anchors(st, [8], [0.5, 1.0, 2.0]), fs, st, vs)
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        assert np.array_equal(v.cpu().numpy(), vref)
+        assert torch.equal(a, g.grid_anchors(fs, st, "cuda"))
+    a2, v2 = T.anchor_pyramid(gens[:3], [sizes[0], (0, 7), sizes[2]], strides[:3], "cuda")
+    assert a2[1].shape == (0, 4) and torch.equal(a2[0], anchors[0]) and torch.equal(a2[2], anchors[2])
+    assert bool(v2[0].all()) and bool(v2[2].all())
+
+
 def test_anchor_grid_edge(ops):
     base = B.base_anchors(16, [8, 16, 32], [0.5, 1.0, 2.0])
     a, v = ops.anchor_grid(torch.from_numpy(base).cuda(), (0, 5), 16)
@@ -88,6 +108,24 @@ def test_nms_bit_exact(ops, n, integer):
     assert int(num.item()) == cnt
     assert np.array_equal(keep.cpu().numpy(), keep_ref)
     assert np.array_equal(kept.cpu().numpy(), kept_ref)
+
+
+@pytest.mark.parametrize("n", [1023, 1024, 1025, 2048 + 17, 5000])
+def test_nms_block_scan_equals_single_wave_scan(ops, n, monkeypatch):
+    """The 1024-thread super-chunk scan and the single-wave scan (TDN_NMS_ONEWAVE=1) give identical keep masks, kept
+    indices and counts — sizes on both sides of the 1024-box super-chunk boundary, a low threshold (few boxes kept:
+    long removal chains) and a high one (almost everything kept: longest serial resolve)."""
+    b, s = rand_boxes(n, 11, False)
+    for thr in (0.05, 0.5, 0.95):
+        monkeypatch.setenv("TDN_NMS_ONEWAVE", "1")
+        k1, i1, n1 = ops.nms(b.cuda(), s.cuda(), thr)
+        monkeypatch.setenv("TDN_NMS_ONEWAVE", "0")
+        k2, i2, n2 = ops.nms(b.cuda(), s.cuda(), thr)
+        assert int(n1.item()) == int(n2.item())
+        assert torch.equal(k1, k2) and torch.equal(i1, i2)
+        keep_ref, kept_ref, cnt = B.nms(b.numpy(), s.numpy(), thr)
+        assert cnt == int(n2.item()) and np.array_equal(k2.cpu().numpy(), keep_ref)
+        assert np.array_equal(i2.cpu().numpy(), kept_ref)
 
 
 def test_nms_edge_cases(ops):

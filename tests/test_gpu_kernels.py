@@ -291,6 +291,47 @@ def test_pack_and_fold(ops):
     assert torch.allclose(sh.cpu(), b - m * g * inv_ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_prepare_group_equals_per_layer_calls(ops, dtype):
+    """tdn_prepare_group (BN fold + pack of many convs in one launch, > 30 members: two launches) is bit-identical to
+    tdn_bn_fold + tdn_pack_conv_weight per layer — contiguous and channels_last 3x3 parameters, 1x1, with and without
+    a BatchNorm behind the conv."""
+    shapes = [(128, 64, 3, 3, True, False), (64, 128, 3, 3, True, True), (256, 64, 1, 1, True, False),
+              (64, 256, 1, 1, False, False), (192, 320, 3, 3, False, True)] * 7      # 35 members
+    entries, refs = [], []
+    for i, (O, I, kh, kw, with_bn, cl) in enumerate(shapes):
+        w = det_tensor((O, I, kh, kw), 300 + i, -1, 1, bf16=False).cuda()
+        if cl:
+            w = w.contiguous(memory_format=torch.channels_last)
+        bn = fold = None
+        scale = None
+        if with_bn:
+            g, b, m, v = (det_tensor((O,), 400 + 4 * i + j, lo, hi, bf16=False).cuda()
+                          for j, (lo, hi) in enumerate(((0.5, 1.5), (-1, 1), (-1, 1), (0.5, 1.5))))
+            bn = (g, b, m, v, 1e-5)
+            fold = torch.empty(3, O, dtype=torch.float32, device="cuda")
+            scale, shift, inv = ops.bn_fold(g, b, m, v, 1e-5)
+            refs.append((scale, shift, inv))
+        else:
+            refs.append(None)
+        wf, wd = ops.pack_conv_weight(w, scale, True, dtype)
+        refs[-1] = (refs[-1], wf, wd)
+        entries.append((w, bn, torch.empty_like(wf), torch.empty_like(wd), fold))
+    ops.prepare_group(entries, dtype)
+    torch.cuda.synchronize()
+    bad = []
+    for idx, ((w, bn, wf, wd, fold), (fr, rf, rd)) in enumerate(zip(entries, refs)):
+        if bn is not None:
+            for j, nm in enumerate(("scale", "shift", "invstd")):
+                if not torch.equal(fold[j], fr[j]):
+                    bad.append((idx, tuple(w.shape), nm, int((fold[j] != fr[j]).sum())))
+        if not torch.equal(wf, rf):
+            bad.append((idx, tuple(w.shape), "w_fwd", int((wf != rf).sum())))
+        if not torch.equal(wd, rd):
+            bad.append((idx, tuple(w.shape), "w_dgrad", int((wd != rd).sum())))
+    assert not bad, bad[:8]
+
+
 def test_bad_shapes_fail_loudly(ops):
     x = nhwc(det_tensor((1, 48, 8, 8), 1))
     w = pack_w(det_tensor((64, 48, 1, 1), 2))

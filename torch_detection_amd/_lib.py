@@ -57,6 +57,30 @@ class WgradItem(ctypes.Structure):
 
 _WI = ctypes.POINTER(WgradItem)
 
+
+class PrepItem(ctypes.Structure):
+    """Mirror of ``tdn_prep_item`` (include/tdn.h): one conv unit of a grouped fold + pack launch."""
+    _fields_ = [
+        ("w", c_void_p), ("w_fwd", c_void_p), ("w_dgrad", c_void_p),
+        ("gamma", c_void_p), ("beta", c_void_p), ("mean", c_void_p), ("var", c_void_p), ("fold", c_void_p),
+        ("s_o", c_i64), ("s_i", c_i64), ("s_h", c_i64), ("s_w", c_i64),
+        ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32), ("kh", ctypes.c_int32), ("kw", ctypes.c_int32),
+        ("eps", c_float), ("reserved", ctypes.c_int32),
+    ]
+
+
+_PI = ctypes.POINTER(PrepItem)
+
+
+class AnchorLevel(ctypes.Structure):
+    """Mirror of ``tdn_anchor_level`` (include/tdn.h)."""
+    _fields_ = [("base_anchors", c_void_p), ("A", ctypes.c_int32), ("featH", ctypes.c_int32),
+                ("featW", ctypes.c_int32), ("stride", ctypes.c_int32), ("valid_h", ctypes.c_int32),
+                ("valid_w", ctypes.c_int32)]
+
+
+_AL = ctypes.POINTER(AnchorLevel)
+
 # name -> (restype, argtypes); must list every symbol of include/tdn.h (tests/test_abi.py checks this)
 SIGNATURES = {
     "tdn_last_error": (ctypes.c_char_p, []),
@@ -65,6 +89,7 @@ SIGNATURES = {
     "tdn_pack_conv_weight": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "tdn_pack_stem_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "tdn_prepare_group": (c_int, [_PI, c_int, c_int, c_void_p]),
     "tdn_conv2d_fwd": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
     "tdn_conv2d_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
     "tdn_conv2d_wgrad_workspace": (c_i64, [c_int] * 8),
@@ -92,6 +117,7 @@ SIGNATURES = {
                                      c_int, c_void_p]),
     "tdn_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "tdn_anchor_grid": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tdn_anchor_pyramid": (c_int, [_AL, c_int, c_void_p, c_void_p, c_void_p]),
     "tdn_bbox_iou_pairwise": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "tdn_nms_workspace": (c_i64, [c_int]),
     "tdn_nms": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,

@@ -62,6 +62,17 @@ class AnchorGenerator(object):
         return ops.anchor_grid(self._base_on(torch.device(device)), featmap_size, stride, valid_size)
 
 
+def anchor_pyramid(generators, featmap_sizes, strides, device='cuda', valid_sizes=None):
+    """Anchors (and valid flags) of every level of a feature pyramid from ONE kernel launch: ``generators[l]`` is the
+    level's :class:`AnchorGenerator`.  Returns (list of per-level (H_l*W_l*A_l, 4) float32 anchors, list of per-level
+    uint8 flags) — views of one allocation each, level order, bit-identical to ``grid_anchors`` / ``valid_flags``
+    called level by level."""
+    dev = torch.device(device)
+    bases = [g._base_on(dev) for g in generators]
+    anchors, valid, counts = ops.anchor_pyramid(bases, featmap_sizes, strides, valid_sizes)
+    return list(torch.split(anchors, counts)), list(torch.split(valid, counts))
+
+
 def bbox_overlaps(bboxes1, bboxes2, mode='iou'):
     """Pairwise IoU (N, M) float32 of inclusive-pixel boxes; strict IEEE fp32, Appendix-B operation order."""
     if mode != 'iou':

@@ -7,6 +7,7 @@
 // order (this file is compiled with -ffp-contract=off; divisions are __fdiv_rn) so that results are
 // bit-identical to oracle/box_ref.c.
 #include "common.h"
+#include <string.h>
 
 // ---- anchor grid -----------------------------------------------------------------------------------
 __global__ void anchor_grid_kernel(const float* __restrict__ base, int A, int featH, int featW, int stride,
@@ -43,6 +44,68 @@ extern "C" int tdn_anchor_grid(const float* base_anchors, int A, int featH, int 
   return 0;
 }
 
+// All levels of a pyramid in ONE launch (five launches of 4..70 us worth of work cost ~9 us each alone): level
+// descriptors in the kernel-argument block, outputs concatenated level after level (order (y, x, anchor) inside a
+// level, exactly as tdn_anchor_grid writes them).
+constexpr int ANCHOR_MAXL = 8;
+struct AnchorLevels {
+  int nlevels, total;
+  int start[ANCHOR_MAXL + 1];      // first anchor of level l; start[nlevels] = total
+  int A[ANCHOR_MAXL], featW[ANCHOR_MAXL], stride[ANCHOR_MAXL], valid_h[ANCHOR_MAXL], valid_w[ANCHOR_MAXL];
+  const float* base[ANCHOR_MAXL];
+};
+
+__global__ void anchor_pyramid_kernel(const AnchorLevels L, float* __restrict__ anchors, uint8_t* valid) {
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < L.total; g += gridDim.x * blockDim.x) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < ANCHOR_MAXL; ++k) l += (k < L.nlevels && g >= L.start[k]) ? 1 : 0;
+    const int i = g - L.start[l];
+    const int A = L.A[l], featW = L.featW[l], stride = L.stride[l];
+    const int a = i % A;
+    const int cell = i / A;
+    const int x = cell % featW, y = cell / featW;
+    const float sx = (float)(x * stride), sy = (float)(y * stride);
+    const f32x4_t b = *(const f32x4_t*)(L.base[l] + a * 4);
+    f32x4_t o;
+    o[0] = b[0] + sx;
+    o[1] = b[1] + sy;
+    o[2] = b[2] + sx;
+    o[3] = b[3] + sy;
+    *(f32x4_t*)(anchors + (int64_t)g * 4) = o;
+    if (valid) valid[g] = (x < L.valid_w[l] && y < L.valid_h[l]) ? 1 : 0;
+  }
+}
+
+extern "C" int tdn_anchor_pyramid(const tdn_anchor_level* levels, int nlevels, float* anchors, uint8_t* valid,
+                                  void* stream) {
+  TDN_CHECK(levels != nullptr && nlevels > 0 && nlevels <= ANCHOR_MAXL, "tdn_anchor_pyramid: 1..%d levels",
+            ANCHOR_MAXL);
+  AnchorLevels L;
+  memset(&L, 0, sizeof(L));
+  L.nlevels = nlevels;
+  int64_t total = 0;
+  for (int l = 0; l < nlevels; ++l) {
+    const tdn_anchor_level& s = levels[l];
+    TDN_CHECK(s.A > 0 && s.featH >= 0 && s.featW >= 0 && s.stride > 0, "tdn_anchor_pyramid: level %d: bad shape", l);
+    TDN_CHECK(s.base_anchors != nullptr, "tdn_anchor_pyramid: level %d: NULL base anchors", l);
+    L.start[l] = (int)total;
+    L.A[l] = s.A; L.featW[l] = s.featW > 0 ? s.featW : 1; L.stride[l] = s.stride;
+    L.valid_h[l] = s.valid_h; L.valid_w[l] = s.valid_w; L.base[l] = s.base_anchors;
+    total += (int64_t)s.featH * s.featW * s.A;
+    TDN_CHECK(total < (1ll << 30), "tdn_anchor_pyramid: too many anchors");
+  }
+  for (int l = nlevels; l <= ANCHOR_MAXL; ++l) L.start[l] = (int)total;
+  L.total = (int)total;
+  if (total == 0) return 0;
+  TDN_CHECK(anchors != nullptr, "tdn_anchor_pyramid: NULL output");
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(anchor_pyramid_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, L, anchors, valid);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- IoU -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float box_area(const f32x4_t b) {
   return __fmul_rn(__fadd_rn(__fsub_rn(b[2], b[0]), 1.0f), __fadd_rn(__fsub_rn(b[3], b[1]), 1.0f));
@@ -55,6 +118,17 @@ __device__ __forceinline__ float box_iou(const f32x4_t a, const float area_a, co
   const float h = fmaxf(__fadd_rn(__fsub_rn(rby, lty), 1.0f), 0.0f);
   const float inter = __fmul_rn(w, h);
   const float area_b = box_area(b);
+  const float uni = __fsub_rn(__fadd_rn(area_a, area_b), inter);
+  return __fdiv_rn(inter, uni);
+}
+
+// the same value with the second box's area supplied (bit-identical: box_area is a pure function of b)
+__device__ __forceinline__ float box_iou2(const f32x4_t a, const float area_a, const f32x4_t b, const float area_b) {
+  const float ltx = fmaxf(a[0], b[0]), lty = fmaxf(a[1], b[1]);
+  const float rbx = fminf(a[2], b[2]), rby = fminf(a[3], b[3]);
+  const float w = fmaxf(__fadd_rn(__fsub_rn(rbx, ltx), 1.0f), 0.0f);
+  const float h = fmaxf(__fadd_rn(__fsub_rn(rby, lty), 1.0f), 0.0f);
+  const float inter = __fmul_rn(w, h);
   const float uni = __fsub_rn(__fadd_rn(area_a, area_b), inter);
   return __fdiv_rn(inter, uni);
 }
@@ -132,26 +206,34 @@ __global__ void nms_scatter_kernel(const float* __restrict__ boxes, const int* _
 }
 
 // (2) 64-bit suppression words: mask[i][cb] bit b  <=>  j = cb*64+b > i  and  iou(i, j) > thr   (sorted order).
+//     One wave per 64 x 64 block: lane l owns COLUMN box j = cb*64 + l (its area computed once); for every row r of
+//     the block the 64 predicates of the lanes are gathered into the row's word with a wavefront ballot, and lane r
+//     keeps it.  Blocks under the diagonal are never read by the scan and are skipped.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ sboxes, int N, float thr, int nblk,
                                                       unsigned long long* __restrict__ mask) {
   const int rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb) return;
-  __shared__ f32x4_t cbox[64];
+  __shared__ f32x4_t rbox[64];
   const int t = threadIdx.x;
-  const int jc = cb * 64 + t;
-  cbox[t] = (jc < N) ? *(const f32x4_t*)(sboxes + (int64_t)jc * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int ir = rb * 64 + t;
+  rbox[t] = (ir < N) ? *(const f32x4_t*)(sboxes + (int64_t)ir * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int j = cb * 64 + t;
+  const bool jvalid = j < N;
+  const f32x4_t bj = jvalid ? *(const f32x4_t*)(sboxes + (int64_t)j * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float area_j = box_area(bj);
   __syncthreads();
-  const int i = rb * 64 + t;
-  if (i >= N) return;
-  const f32x4_t bi = *(const f32x4_t*)(sboxes + (int64_t)i * 4);
-  const float area_i = box_area(bi);
-  unsigned long long word = 0ull;
-  const int ncol = min(64, N - cb * 64);
-  for (int b = 0; b < ncol; ++b) {
-    const int j = cb * 64 + b;
-    if (j > i && box_iou(bi, area_i, cbox[b]) > thr) word |= 1ull << b;
+  unsigned long long mine = 0ull;
+  const int nrow = min(64, N - rb * 64);
+  for (int r = 0; r < nrow; ++r) {
+    const int i = rb * 64 + r;
+    const f32x4_t bi = rbox[r];                       // LDS broadcast
+    const float area_i = box_area(bi);
+    // argument order as in the oracle's nms: iou(box_i, box_j)
+    const bool hit = jvalid && j > i && box_iou2(bi, area_i, bj, area_j) > thr;
+    const unsigned long long word = __ballot(hit);
+    mine = (t == r) ? word : mine;
   }
-  mask[(int64_t)i * nblk + cb] = word;
+  if (ir < N) mask[(int64_t)ir * nblk + cb] = mine;
 }
 
 // (3) serial keep scan by ONE wave: 64-box chunks; within a chunk the diagonal words are resolved with
@@ -211,6 +293,119 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
   if (lane == 0) *num_kept = cnt;
 }
 
+// (3') the same scan by a 1024-thread workgroup, in super-chunks of 16 chunks (1024 boxes):
+//   A  all threads: the super-chunk's 1024 x 16-word diagonal band of the mask -> LDS (128 KB), one row per thread;
+//   B  wave 0: the 16 chunks in order, entirely from LDS — resolve the diagonal word (ctz / readlane), emit keep flags
+//      and compacted indices (popcount of the kept bits below the lane = the lane's rank in the wave's ballot), OR the
+//      kept rows into the removal words of the later chunks of the band (lane = word);
+//   C  all threads: OR the super-chunk's kept rows into the removal bitmap for every word past the band — wave w takes
+//      chunk w's rows, lanes take words (row-contiguous 512-byte reads), LDS atomic OR.
+// The single-wave kernel above pays one global-memory round trip per chunk on its critical path (157 at N = 10k);
+// here the serial part touches LDS only and global latency is paid twice per 1024 boxes.
+constexpr int NMS_SC = 16;                       // chunks per super-chunk
+constexpr int NMS_SCROWS = NMS_SC * 64;          // 1024 rows = threads
+constexpr int NMS_DPITCH = NMS_SCROWS + 1;       // words; odd pitch: lanes reading one row of 16 bands hit 16 banks pairs
+constexpr int NMS_BLOCK_MAX_NBLK = 3500;         // removal bitmap + band must fit 160 KB of LDS
+
+__global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned long long* __restrict__ mask,
+                                                              const int* __restrict__ order, int N, int nblk,
+                                                              uint8_t* keep, int64_t* kept_idx, int* num_kept) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
+  unsigned long long* remv = sm;                                  // [nblk]
+  unsigned long long* D = sm + ((nblk + 1) & ~1);                 // [NMS_SC][NMS_DPITCH]
+  unsigned long long* kbits = D + NMS_SC * NMS_DPITCH;            // [NMS_SC]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int w = tid; w < nblk; w += 1024) remv[w] = 0ull;
+  int cnt = 0;                                                    // wave 0 only
+  const int nsuper = (nblk + NMS_SC - 1) / NMS_SC;
+  for (int s = 0; s < nsuper; ++s) {
+    const int c0 = s * NMS_SC;
+    const int nch = min(NMS_SC, nblk - c0);
+    // ---- A: diagonal band -> LDS ----
+    {
+      const int row = c0 * 64 + tid;
+      const unsigned long long* src = mask + (int64_t)row * nblk + c0;
+#pragma unroll
+      for (int k = 0; k < NMS_SC; ++k) {
+        unsigned long long v = 0ull;
+        if (row < N && k < nch) v = src[k];
+        D[k * NMS_DPITCH + tid] = v;
+      }
+    }
+    __syncthreads();
+    // ---- B: serial resolution of the band, wave 0 ----
+    if (wave == 0) {
+      for (int kc = 0; kc < nch; ++kc) {
+        const int c = c0 + kc;
+        const int i = c * 64 + lane;
+        const unsigned long long diag = D[kc * NMS_DPITCH + kc * 64 + lane];
+        const int nvalid = min(64, N - c * 64);
+        unsigned long long alive = ~remv[c];
+        if (nvalid < 64) alive &= (1ull << nvalid) - 1ull;
+        unsigned long long keepbits = 0ull;
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+        while (alive) {
+          const int b = __builtin_ctzll(alive);
+          keepbits |= 1ull << b;
+          alive &= ~(1ull << b);
+          const unsigned lo = __builtin_amdgcn_readlane(dlo, b), hi = __builtin_amdgcn_readlane(dhi, b);
+          alive &= ~(((unsigned long long)hi << 32) | lo);
+        }
+        if (i < N) {
+          const bool k = (keepbits >> lane) & 1ull;
+          const int oi = order[i];
+          keep[oi] = k ? 1 : 0;
+          if (k) kept_idx[cnt + __builtin_popcountll(keepbits & ((1ull << lane) - 1ull))] = (int64_t)oi;
+        }
+        cnt += __builtin_popcountll(keepbits);
+        if (lane == 0) kbits[kc] = keepbits;
+        const int k2 = kc + 1 + lane;                 // later chunk of the band handled by this lane
+        if (k2 < nch) {
+          unsigned long long acc = 0ull, kb = keepbits;
+          const unsigned long long* col = D + k2 * NMS_DPITCH + kc * 64;
+          while (kb) {
+            const int b0 = __builtin_ctzll(kb); kb &= kb - 1;
+            unsigned long long v0 = col[b0], v1 = 0ull;
+            if (kb) { const int b1 = __builtin_ctzll(kb); kb &= kb - 1; v1 = col[b1]; }
+            acc |= v0 | v1;
+          }
+          remv[c0 + k2] |= acc;
+        }
+        __threadfence_block();                        // lane k2's remv write before every lane's read of it next round
+      }
+    }
+    __syncthreads();
+    // ---- C: kept rows of the band -> removal words past the band ----
+    const int wbeg = c0 + nch;
+    if (wbeg < nblk && wave < nch) {
+      const unsigned long long keepbits = kbits[wave];
+      const int64_t row0 = (int64_t)(c0 + wave) * 64;
+      for (int wbase = wbeg; wbase < nblk; wbase += 64) {
+        const int w = wbase + lane;
+        if (w < nblk) {
+          unsigned long long acc = 0ull, kb = keepbits;
+          while (kb) {   // up to 4 independent row loads in flight
+            const int b0 = __builtin_ctzll(kb); kb &= kb - 1;
+            unsigned long long v0 = mask[(row0 + b0) * nblk + w], v1 = 0ull, v2 = 0ull, v3 = 0ull;
+            if (kb) { const int b1 = __builtin_ctzll(kb); kb &= kb - 1; v1 = mask[(row0 + b1) * nblk + w]; }
+            if (kb) { const int b2 = __builtin_ctzll(kb); kb &= kb - 1; v2 = mask[(row0 + b2) * nblk + w]; }
+            if (kb) { const int b3 = __builtin_ctzll(kb); kb &= kb - 1; v3 = mask[(row0 + b3) * nblk + w]; }
+            acc |= (v0 | v1) | (v2 | v3);
+          }
+          if (acc) atomicOr(&remv[w], acc);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    for (int k = cnt + lane; k < N; k += 64) kept_idx[k] = -1;
+    if (lane == 0) *num_kept = cnt;
+  }
+}
+
 static inline int64_t align256(int64_t x) { return (x + 255) & ~255ll; }
 
 extern "C" int64_t tdn_nms_workspace(int N) {
@@ -251,8 +446,22 @@ extern "C" int tdn_nms(const float* boxes, const float* scores, int N, float iou
   TDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, st, sboxes, N, iou_thr, nblk, mask);
   TDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)nblk * 8, st, mask, order, N, nblk, keep, kept_idx,
-                     num_kept);
+  const bool one_wave = getenv("TDN_NMS_ONEWAVE") && getenv("TDN_NMS_ONEWAVE")[0] == '1';   // A/B runs
+  if (nblk <= NMS_BLOCK_MAX_NBLK && !one_wave) {
+    const size_t lds = (size_t)(((nblk + 1) & ~1) + NMS_SC * NMS_DPITCH + NMS_SC) * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)nms_scan_block_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(nms scan LDS) failed: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_scan_block_kernel, dim3(1), dim3(1024), lds, st, mask, order, N, nblk, keep, kept_idx,
+                       num_kept);
+  } else {
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)nblk * 8, st, mask, order, N, nblk, keep, kept_idx,
+                       num_kept);
+  }
   TDN_LAUNCH_CHECK();
   return 0;
 }

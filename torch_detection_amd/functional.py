@@ -134,6 +134,11 @@ class ConvUnit(object):
         capturing = REPACK_IN_CAPTURE and torch.cuda.is_current_stream_capturing()
         if key == self.key and not capturing:
             return self
+        pending = getattr(_defer, 'pending', None)
+        if pending is not None and w.dtype == torch.float32 and not (
+                self.is_stem or self.groups > 1 or self.gn or self.bnt or self.bias_and_norm):
+            pending.append((self, key))   # plain conv (+ eval-mode BN): prepared with the others in one launch
+            return self
         # same sources as last time (only their contents may differ): overwrite the buffers in place — during capture
         # that is what makes the graph self-contained, and addresses other captured nodes hold stay valid
         layout = (w.device, self.dtype, tuple(w.shape), self.gn, self.bnt, self.bn is not None,
@@ -179,6 +184,56 @@ class ConvUnit(object):
                     out=(self.w_fwd, self.w_dgrad) if reuse and self.w_dgrad is not None else None)
         self.key = key
         return self
+
+
+# Units refreshed inside ``with batched_refresh():`` (the nets' builders) are collected and their fold + pack work is
+# enqueued as ONE grouped launch per 30 units when the block exits (ops.prepare_group) — a training step re-derives
+# the operands of all 53 + 8 convs of ResNet-50-FPN after every optimizer update.
+_defer = threading.local()
+
+
+class batched_refresh(object):
+    def __enter__(self):
+        self.outer = getattr(_defer, 'pending', None)
+        if self.outer is None:
+            _defer.pending = []
+        return self
+
+    def __exit__(self, *exc):
+        if self.outer is None:
+            pending, _defer.pending = _defer.pending, None
+            if exc[0] is None:
+                _flush_refresh(pending)
+        return False
+
+
+def _flush_refresh(pending):
+    by_dtype = {}
+    for u, key in pending:
+        w = u.conv.weight
+        O, I, kh, kw = w.shape
+        layout = (w.device, u.dtype, tuple(w.shape), False, False, u.bn is not None, u.conv.bias is not None)
+        reuse = u.w_fwd is not None and u.w_dgrad is not None and layout == u._layout
+        u._layout = layout
+        if not reuse:
+            u.w_fwd = torch.empty(O, kh, kw, I, dtype=u.dtype, device=w.device)
+            u.w_dgrad = torch.empty(I, kh, kw, O, dtype=u.dtype, device=w.device)
+            u._fold = torch.empty(3, O, dtype=torch.float32, device=w.device) if u.bn is not None else None
+        bn = None
+        if u.bn is not None:
+            if u._fold is None:
+                u._fold = torch.empty(3, O, dtype=torch.float32, device=w.device)
+            bn = (u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var, u.bn.eps)
+            u.scale, u.shift, u.invstd = u._fold[0], u._fold[1], u._fold[2]
+            u.mean = u.bn.running_mean
+        else:
+            u.scale = u.invstd = u.mean = None
+            u.shift = u.conv.bias.detach() if u.conv.bias is not None else None
+        by_dtype.setdefault(u.dtype, []).append((w, bn, u.w_fwd, u.w_dgrad, u._fold if bn is not None else None))
+        u.key = key
+    with torch.no_grad():
+        for dtype, entries in by_dtype.items():
+            ops.prepare_group(entries, dtype)
 
 
 # Whether units re-run their pack / fold kernels inside a hipGraph capture (see ConvUnit.refresh).  GraphedStep sets

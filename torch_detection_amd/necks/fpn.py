@@ -67,8 +67,9 @@ class FPN(nn.Module):
     def hip_net(self, dtype=None):
         if dtype is None:
             dtype = getattr(self, 'compute_dtype', torch.bfloat16)
-        lat = [m.hip_unit(dtype) for m in self.lateral_convs]
-        fpn = [m.hip_unit(dtype) for m in self.fpn_convs]
+        with HF.batched_refresh():
+            lat = [m.hip_unit(dtype) for m in self.lateral_convs]
+            fpn = [m.hip_unit(dtype) for m in self.fpn_convs]
         return HF.FPNNet(lat, fpn, self.start_level, self.backbone_end_level, self.num_outs,
                          self.add_extra_convs, self.num_ins)
 

@@ -129,6 +129,36 @@ def pack_conv_weight(w, scale=None, want_dgrad=True, dtype=BF16, out=None):
     return w_fwd, w_dg
 
 
+def prepare_group(entries, dtype=BF16):
+    """BN fold + weight pack of many plain conv units in one grouped launch (``tdn_prepare_group``).
+
+    entries: list of (w fp32 OIHW parameter (any strides), bn or None, w_fwd, w_dgrad, fold) with bn = (gamma, beta,
+    running_mean, running_var, eps) and the outputs preallocated: w_fwd [O,kh,kw,I], w_dgrad [I,kh,kw,O] in ``dtype``,
+    fold float32 (3, O) (None without bn).  Bit-identical to bn_fold + pack_conv_weight per entry."""
+    n = len(entries)
+    if n == 0:
+        return
+    arr = (_lib.PrepItem * n)()
+    for it, (w, bn, w_fwd, w_dg, fold) in zip(arr, entries):
+        w = w.detach()
+        if w.dtype != torch.float32 or not w.is_cuda or w.dim() != 4:
+            raise ValueError("weight must be a CUDA float32 4-D tensor")
+        O, I, kh, kw = w.shape
+        _pack_out((w_fwd, w_dg), [(O, kh, kw, I), (I, kh, kw, O)], dtype, "prepare_group")
+        it.w, it.w_fwd, it.w_dgrad = w.data_ptr(), w_fwd.data_ptr(), w_dg.data_ptr()
+        it.s_o, it.s_i, it.s_h, it.s_w = w.stride()
+        it.Cout, it.Cin, it.kh, it.kw = O, I, kh, kw
+        if bn is not None:
+            gamma, beta, mean, var, eps = bn
+            for t, nm in ((gamma, "gamma"), (beta, "beta"), (mean, "running_mean"), (var, "running_var")):
+                _chk_vec(t.detach(), nm, O)
+            if fold is None or tuple(fold.shape) != (3, O) or fold.dtype != torch.float32 or not fold.is_contiguous():
+                raise ValueError("prepare_group: fold must be a contiguous float32 (3, %d) tensor" % O)
+            it.gamma, it.beta, it.mean, it.var = gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr()
+            it.fold, it.eps = fold.data_ptr(), float(eps)
+    _lib.check(_lib.load().tdn_prepare_group(arr, n, dtype_code(dtype), _lib.stream_ptr()), "tdn_prepare_group")
+
+
 def pack_stem_weight(w, dtype=BF16, out=None):
     w = w.detach()
     if w.dtype != torch.float32 or not w.is_cuda or tuple(w.shape[1:]) != (3, 7, 7) or not w.is_contiguous():
@@ -522,6 +552,31 @@ def anchor_grid(base_anchors, featmap_size, stride, valid_size=None):
     _lib.check(_lib.load().tdn_anchor_grid(_ptr(base_anchors), A, fh, fw, int(stride), int(vh), int(vw),
                                            _ptr(anchors), _ptr(valid), _lib.stream_ptr()), "tdn_anchor_grid")
     return anchors, valid
+
+
+def anchor_pyramid(bases, featmap_sizes, strides, valid_sizes=None):
+    """All levels of an anchor pyramid in ONE launch (``tdn_anchor_pyramid``).  bases: per-level base anchors (A_l, 4)
+    on the GPU; returns (anchors (sum, 4) float32, valid (sum,) uint8, per-level row counts) — level after level, the
+    rows of a level exactly what ``anchor_grid`` returns for it."""
+    n = len(bases)
+    if not (n == len(featmap_sizes) == len(strides)) or n == 0 or n > 8 or \
+            (valid_sizes is not None and len(valid_sizes) != n):
+        raise ValueError("anchor_pyramid takes 1..8 levels with one base / size / stride each")
+    arr = (_lib.AnchorLevel * n)()
+    counts = []
+    for l, (base, (fh, fw), st) in enumerate(zip(bases, featmap_sizes, strides)):
+        _chk_boxes(base, "base_anchors[%d]" % l)
+        vh, vw = valid_sizes[l] if valid_sizes is not None else (fh, fw)
+        arr[l].base_anchors, arr[l].A = base.data_ptr(), base.shape[0]
+        arr[l].featH, arr[l].featW, arr[l].stride, arr[l].valid_h, arr[l].valid_w = int(fh), int(fw), int(st), int(vh), int(vw)
+        counts.append(int(fh) * int(fw) * base.shape[0])
+    dev = bases[0].device
+    total = sum(counts)
+    anchors = torch.empty(total, 4, dtype=torch.float32, device=dev)
+    valid = torch.empty(total, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.load().tdn_anchor_pyramid(arr, n, _ptr(anchors), _ptr(valid), _lib.stream_ptr()),
+               "tdn_anchor_pyramid")
+    return anchors, valid, counts
 
 
 def bbox_iou_pairwise(a, b):
