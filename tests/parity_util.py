@@ -23,7 +23,7 @@ def nchw(t):
 
 
 def run_teacher_forced(T, depth, shape, dev="cuda", threads=None, dtype=torch.bfloat16, cot_scale=1.0,
-                       res_gain=1.0):
+                       res_gain=1.0, end_to_end=True):
     """Returns a dict of measured relative-L2 errors (forward in situ, backward teacher-forced, and the plain
     end-to-end distances to the fp32 autograd oracle for the record)."""
     from oracle import sched_ref as S
@@ -46,6 +46,7 @@ def run_teacher_forced(T, depth, shape, dev="cuda", threads=None, dtype=torch.bf
     rb.compute_dtype = rf.compute_dtype = dtype   # bf16 (default) or fp16 operands; parameters stay fp32
     x = det_tensor(shape, 700, -2, 2)
     cap = {}
+    bwd_launches = []
     HF.DEBUG_CAPTURE = cap
     try:
         outs = rf(rb(x.to(dev)))
@@ -53,7 +54,12 @@ def run_teacher_forced(T, depth, shape, dev="cuda", threads=None, dtype=torch.bf
         HF.DEBUG_CAPTURE = None
     # cot_scale: the loss scale of an fp16 run (a power of two, so the cotangents stay exactly representable)
     cots = [det_tensor(tuple(o.shape), 710 + i, -1, 1) * cot_scale for i, o in enumerate(outs)]
-    torch.autograd.backward(outs, [c.to(dev).to(o.dtype) for c, o in zip(cots, outs)])
+    HF.DEBUG_BWD = bwd_launches
+    try:
+        torch.autograd.backward(outs, [c.to(dev).to(o.dtype) for c, o in zip(cots, outs)])
+        torch.cuda.synchronize()
+    finally:
+        HF.DEBUG_BWD = None
     assert all(o.dtype == dtype for o in outs), [o.dtype for o in outs]
     got = {}
     for prefix, mod in (("backbone.", rb), ("neck.", rf)):
@@ -91,6 +97,8 @@ def run_teacher_forced(T, depth, shape, dev="cuda", threads=None, dtype=torch.bf
         worst = max(worst, rel_l2(g_outs[i], sch.fpn_u[i].fwd(g_lat[i])))
     worst = max(worst, rel_l2(g_outs[4], g_outs[3][:, :, ::2, ::2]))
     fwd["fpn_worst"] = worst
+    # ---- backward, launch by launch, from the GPU's own operands of that launch ----
+    bwd = backward_in_situ(sch, rb, rf, bwd_launches, S.rnd(x, dtype))
     # ---- backward with the GPU's saved activations ----
     sch.x = S.rnd(x, dtype)
     sch.out_shapes = [tuple(o.shape) for o in g_outs]
@@ -101,13 +109,75 @@ def run_teacher_forced(T, depth, shape, dev="cuda", threads=None, dtype=torch.bf
     srt = sorted(eg.values())
     worst_g = max(eg.items(), key=lambda kv: kv[1])
     # ---- for the record: end-to-end distance to the fp32 autograd oracle (== the reference's arithmetic) ----
-    ref_outs, ref32 = O.resnet_fpn_fwd_bwd(sdb, sdf, x, depth, cots)
-    eo32 = [rel_l2(a, b) for a, b in zip(g_outs, ref_outs)]
-    eg32 = sorted(rel_l2(got[k], ref32[k]) for k in got)
+    if end_to_end:
+        ref_outs, ref32 = O.resnet_fpn_fwd_bwd(sdb, sdf, x, depth, cots)
+        eo32 = [rel_l2(a, b) for a, b in zip(g_outs, ref_outs)]
+        eg32 = sorted(rel_l2(got[k], ref32[k]) for k in got)
+    else:   # full-size runs skip the fp32 autograd pass of the whole net (the in-situ checks are the point there)
+        eo32, eg32 = [0.0], [0.0]
     return {"forward_in_situ": fwd,
+            "backward_in_situ": bwd,
             "backward_teacher_forced": {"grad_worst": list(worst_g), "grad_median": srt[len(srt) // 2]},
             "end_to_end_vs_fp32_autograd": {"out": eo32, "grad_median": eg32[len(eg32) // 2],
                                             "grad_worst": eg32[-1]}}
+
+
+def backward_in_situ(sch, rb, rf, launches, x_img):
+    """Every dgrad launch and every weight-gradient member of the GPU's backward pass, recomputed on the CPU by the
+    schedule oracle's unit of the same layer from the GPU's OWN operands of that launch (the activation gradient g it
+    read, the addend / ReLU-mask tensors of its epilogue, the saved forward input).  Identical inputs on both sides:
+    what is left is one layer's arithmetic — fp32 accumulation order and one rounding to the 16-bit storage type —
+    so the per-launch bound is the north star's 1e-3, for every layer, at any depth.
+    Returns the worst relative-L2 error per kind and where it occurred."""
+    from torch_detection_amd import ops
+    units = {}
+    conv_name = {}
+    for prefix, mod in (("backbone.", rb), ("neck.", rf)):
+        for name, m in mod.named_modules():
+            if isinstance(m, torch.nn.Conv2d):
+                conv_name[id(m)] = prefix + name
+    units["backbone.conv1"] = sch.stem
+    for blk in sch.blocks:
+        units["backbone.%s.conv1" % blk.p] = blk.u1
+        units["backbone.%s.conv2" % blk.p] = blk.u2
+        if blk.u3 is not None:
+            units["backbone.%s.conv3" % blk.p] = blk.u3
+        if blk.ud is not None:
+            units["backbone.%s.downsample.0" % blk.p] = blk.ud
+    for i in range(sch.nlat):
+        units["neck.lateral_convs.%d.conv" % i] = sch.lat_u[i]
+        units["neck.fpn_convs.%d.conv" % i] = sch.fpn_u[i]
+    worst = {"dgrad": [0.0, None], "dw": [0.0, None], "dgamma": [0.0, None], "dbeta_or_dbias": [0.0, None]}
+    count = {"dgrad": 0, "wgrad": 0}
+
+    def upd(kind, err, name):
+        if err > worst[kind][0]:
+            worst[kind] = [err, name]
+
+    for rec in launches:
+        name = conv_name[id(rec[1].conv)]
+        ref_u = units[name]
+        if rec[0] == 'dgrad':
+            _, u, g, in_hw, addend, mode, mask_src, dx = rec
+            a = nchw(addend) if addend is not None and mode != ops.ADD_NONE else None
+            ref = ref_u.dgrad(nchw(g), in_hw, a, 'same' if mode == ops.ADD_SAME else 'sumpool',
+                              nchw(mask_src) if mask_src is not None else None)
+            upd("dgrad", rel_l2(nchw(dx), ref), name)
+            count["dgrad"] += 1
+        else:
+            _, u, x_in, g, img_hw, (dw, dg, db) = rec
+            xin = x_img if u.is_stem else nchw(x_in)
+            ref = ref_u.wgrad(xin, nchw(g))
+            upd("dw", rel_l2(dw.detach().float().cpu(), ref[0]), name)
+            if len(ref) == 3:
+                upd("dgamma", rel_l2(dg.float().cpu(), ref[1]), name)
+                upd("dbeta_or_dbias", rel_l2(db.float().cpu(), ref[2]), name)
+            elif len(ref) == 2:
+                upd("dbeta_or_dbias", rel_l2(db.float().cpu(), ref[1]), name)
+            count["wgrad"] += 1
+    out = {k: v for k, v in worst.items()}
+    out["launches"] = count
+    return out
 
 
 # bounds (relative L2); see module docstring
@@ -121,9 +191,17 @@ BWD_TEACHER_TOL_DEEP = 1.2e-1
 FWD_END_TO_END_TOL = 2e-2   # bf16 activations vs the fp32 reference path (~1e-2 expected)
 
 
+BWD_IN_SITU_TOL = 1e-3      # every dgrad launch / weight-gradient member on its own operands (fp32 outputs of the
+                            # weight gradients: accumulation order only; dgrad: one 16-bit rounding, like the forward)
+
+
 def check(res, depth=50):
     f = res["forward_in_situ"]
     assert max(f.values()) <= FWD_IN_SITU_TOL, f
+    b = res["backward_in_situ"]
+    assert b["launches"]["dgrad"] > 0 and b["launches"]["wgrad"] > 0, b
+    for kind in ("dgrad", "dw", "dgamma", "dbeta_or_dbias"):
+        assert b[kind][0] <= BWD_IN_SITU_TOL, (kind, b[kind])
     tol = BWD_TEACHER_TOL if depth <= 50 else BWD_TEACHER_TOL_DEEP
     assert res["backward_teacher_forced"]["grad_worst"][1] <= tol, res["backward_teacher_forced"]
     assert res["backward_teacher_forced"]["grad_median"] <= 3e-2, res["backward_teacher_forced"]

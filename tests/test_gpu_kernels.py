@@ -278,6 +278,10 @@ def test_pack_and_fold(ops):
     assert torch.equal(wf.float().cpu(), w.bfloat16().float().permute(0, 2, 3, 1))
     ref_d = (w.bfloat16().float() * scale.view(-1, 1, 1, 1)).bfloat16().float().permute(1, 2, 3, 0)
     assert torch.equal(wd.float().cpu(), ref_d)
+    # float16 operands: torch's own two-step rounding (fp32 product, then .half()), not a fused single rounding
+    wf16, wd16 = ops.pack_conv_weight(w.cuda(), scale.cuda(), True, torch.float16)
+    assert torch.equal(wf16.float().cpu(), w.half().float().permute(0, 2, 3, 1))
+    assert torch.equal(wd16.cpu(), (w.half().float() * scale.view(-1, 1, 1, 1)).half().permute(1, 2, 3, 0))
     # channels_last-strided parameter gives the same packing
     wcl = w.cuda().contiguous(memory_format=torch.channels_last)
     wf2, _ = ops.pack_conv_weight(wcl, scale.cuda())

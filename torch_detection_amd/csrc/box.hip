@@ -295,16 +295,20 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
 
 // (3') the same scan by a 1024-thread workgroup, in super-chunks of 16 chunks (1024 boxes):
 //   A  all threads: the super-chunk's 1024 x 16-word diagonal band of the mask -> LDS (128 KB), one row per thread;
-//   B  wave 0: the 16 chunks in order, entirely from LDS — resolve the diagonal word (ctz / readlane), emit keep flags
-//      and compacted indices (popcount of the kept bits below the lane = the lane's rank in the wave's ballot), OR the
-//      kept rows into the removal words of the later chunks of the band (lane = word);
-//   C  all threads: OR the super-chunk's kept rows into the removal bitmap for every word past the band — wave w takes
-//      chunk w's rows, lanes take words (row-contiguous 512-byte reads), LDS atomic OR.
-// The single-wave kernel above pays one global-memory round trip per chunk on its critical path (157 at N = 10k);
-// here the serial part touches LDS only and global latency is paid twice per 1024 boxes.
+//   B  wave 0: the 16 chunks in order, entirely from LDS.  Resolving a chunk's diagonal word is serial only over the
+//      boxes that overlap a LATER box of the same chunk (rows with a non-zero diagonal word — found with one wavefront
+//      ballot; a box with an all-zero row suppresses nothing inside the chunk, so its fate is simply its bit once the
+//      earlier non-zero rows have been applied): ~1 iteration per chunk on sparse inputs instead of one per kept box.
+//      Then keep flags and compacted indices are written (a lane's slot = kept boxes before the chunk + popcount of the
+//      kept bits below the lane, i.e. its rank in the ballot), and the kept rows are OR-ed into the removal words of
+//      the band's later chunks: lane = (word, quarter of the rows), quarters combined with two wave shuffles;
+//   C  all threads: thread t = row t of the band; a kept row streams its words past the band (contiguous in memory)
+//      and ORs them into the removal bitmap with LDS atomics.
+// The single-wave kernel above pays a global-memory round trip per chunk on its critical path (157 at N = 10k) and
+// one serial step per kept box; here the serial part touches LDS only and global latency is paid twice per 1024 boxes.
 constexpr int NMS_SC = 16;                       // chunks per super-chunk
 constexpr int NMS_SCROWS = NMS_SC * 64;          // 1024 rows = threads
-constexpr int NMS_DPITCH = NMS_SCROWS + 1;       // words; odd pitch: lanes reading one row of 16 bands hit 16 banks pairs
+constexpr int NMS_DPITCH = NMS_SCROWS + 1;       // words; odd pitch: the 16 words of one row sit in 16 different banks
 constexpr int NMS_BLOCK_MAX_NBLK = 3500;         // removal bitmap + band must fit 160 KB of LDS
 
 __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned long long* __restrict__ mask,
@@ -323,9 +327,9 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
   for (int s = 0; s < nsuper; ++s) {
     const int c0 = s * NMS_SC;
     const int nch = min(NMS_SC, nblk - c0);
+    const int row = c0 * 64 + tid;
     // ---- A: diagonal band -> LDS ----
     {
-      const int row = c0 * 64 + tid;
       const unsigned long long* src = mask + (int64_t)row * nblk + c0;
 #pragma unroll
       for (int k = 0; k < NMS_SC; ++k) {
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
     __syncthreads();
     // ---- B: serial resolution of the band, wave 0 ----
     if (wave == 0) {
+      const int tw = lane & 15, part = lane >> 4;     // band OR: target word offset, quarter of the chunk's rows
       for (int kc = 0; kc < nch; ++kc) {
         const int c = c0 + kc;
         const int i = c * 64 + lane;
@@ -344,15 +349,17 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
         const int nvalid = min(64, N - c * 64);
         unsigned long long alive = ~remv[c];
         if (nvalid < 64) alive &= (1ull << nvalid) - 1ull;
-        unsigned long long keepbits = 0ull;
         const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-        while (alive) {
-          const int b = __builtin_ctzll(alive);
-          keepbits |= 1ull << b;
-          alive &= ~(1ull << b);
+        unsigned long long todo = alive & __ballot(diag != 0ull);   // boxes that can suppress inside this chunk
+        while (todo) {
+          const int b = __builtin_ctzll(todo);
           const unsigned lo = __builtin_amdgcn_readlane(dlo, b), hi = __builtin_amdgcn_readlane(dhi, b);
-          alive &= ~(((unsigned long long)hi << 32) | lo);
+          const unsigned long long rowbits = ((unsigned long long)hi << 32) | lo;   // only bits above b
+          alive &= ~rowbits;
+          todo &= ~rowbits;
+          todo &= todo - 1;                           // b itself is done (and kept)
         }
+        const unsigned long long keepbits = alive;
         if (i < N) {
           const bool k = (keepbits >> lane) & 1ull;
           const int oi = order[i];
@@ -361,41 +368,45 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
         }
         cnt += __builtin_popcountll(keepbits);
         if (lane == 0) kbits[kc] = keepbits;
-        const int k2 = kc + 1 + lane;                 // later chunk of the band handled by this lane
-        if (k2 < nch) {
-          unsigned long long acc = 0ull, kb = keepbits;
-          const unsigned long long* col = D + k2 * NMS_DPITCH + kc * 64;
-          while (kb) {
-            const int b0 = __builtin_ctzll(kb); kb &= kb - 1;
-            unsigned long long v0 = col[b0], v1 = 0ull;
-            if (kb) { const int b1 = __builtin_ctzll(kb); kb &= kb - 1; v1 = col[b1]; }
-            acc |= v0 | v1;
+        // kept rows -> removal words of the band's later chunks
+        {
+          const int k2 = kc + 1 + tw;
+          unsigned long long acc = 0ull;
+          if (k2 < nch) {
+            unsigned long long kb = (keepbits >> (part * 16)) & 0xFFFFull;
+            const unsigned long long* col = D + k2 * NMS_DPITCH + kc * 64 + part * 16;
+            while (kb) {
+              const int b0 = __builtin_ctzll(kb); kb &= kb - 1;
+              unsigned long long v0 = col[b0], v1 = 0ull, v2 = 0ull, v3 = 0ull;
+              if (kb) { const int b1 = __builtin_ctzll(kb); kb &= kb - 1; v1 = col[b1]; }
+              if (kb) { const int b2 = __builtin_ctzll(kb); kb &= kb - 1; v2 = col[b2]; }
+              if (kb) { const int b3 = __builtin_ctzll(kb); kb &= kb - 1; v3 = col[b3]; }
+              acc |= (v0 | v1) | (v2 | v3);
+            }
           }
-          remv[c0 + k2] |= acc;
+          acc |= __shfl_xor(acc, 16, 64);
+          acc |= __shfl_xor(acc, 32, 64);
+          if (part == 0 && k2 < nch && acc) remv[c0 + k2] |= acc;
         }
-        __threadfence_block();                        // lane k2's remv write before every lane's read of it next round
+        __threadfence_block();                        // the removal words written above are read by every lane next round
       }
     }
     __syncthreads();
     // ---- C: kept rows of the band -> removal words past the band ----
     const int wbeg = c0 + nch;
-    if (wbeg < nblk && wave < nch) {
-      const unsigned long long keepbits = kbits[wave];
-      const int64_t row0 = (int64_t)(c0 + wave) * 64;
-      for (int wbase = wbeg; wbase < nblk; wbase += 64) {
-        const int w = wbase + lane;
-        if (w < nblk) {
-          unsigned long long acc = 0ull, kb = keepbits;
-          while (kb) {   // up to 4 independent row loads in flight
-            const int b0 = __builtin_ctzll(kb); kb &= kb - 1;
-            unsigned long long v0 = mask[(row0 + b0) * nblk + w], v1 = 0ull, v2 = 0ull, v3 = 0ull;
-            if (kb) { const int b1 = __builtin_ctzll(kb); kb &= kb - 1; v1 = mask[(row0 + b1) * nblk + w]; }
-            if (kb) { const int b2 = __builtin_ctzll(kb); kb &= kb - 1; v2 = mask[(row0 + b2) * nblk + w]; }
-            if (kb) { const int b3 = __builtin_ctzll(kb); kb &= kb - 1; v3 = mask[(row0 + b3) * nblk + w]; }
-            acc |= (v0 | v1) | (v2 | v3);
-          }
-          if (acc) atomicOr(&remv[w], acc);
-        }
+    if (wbeg < nblk && row < N && ((kbits[tid >> 6] >> (tid & 63)) & 1ull)) {
+      const unsigned long long* src = mask + (int64_t)row * nblk;
+      int w = wbeg;
+      for (; w + 4 <= nblk; w += 4) {                 // 4 independent loads in flight per thread
+        const unsigned long long v0 = src[w], v1 = src[w + 1], v2 = src[w + 2], v3 = src[w + 3];
+        if (v0) atomicOr(&remv[w], v0);
+        if (v1) atomicOr(&remv[w + 1], v1);
+        if (v2) atomicOr(&remv[w + 2], v2);
+        if (v3) atomicOr(&remv[w + 3], v3);
+      }
+      for (; w < nblk; ++w) {
+        const unsigned long long v = src[w];
+        if (v) atomicOr(&remv[w], v);
       }
     }
     __syncthreads();

@@ -90,6 +90,15 @@ __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// a * b as an fp32 value of its own.  Without the barrier the backend may fold  (f16)(a * b)  into v_fma_mixlo_f16 —
+// ONE rounding of the exact product instead of the two of torch's  (x.float() * s).half()  — and does so in some
+// kernels and not in others (seen in the weight-pack kernels: 1-4 elements per tensor differed by an ulp).
+__device__ __forceinline__ float mul_f32_rounded(float a, float b) {
+  float p = a * b;
+  asm volatile("" : "+v"(p));
+  return p;
+}
+
 // Upper knee of nn.ReLU6 for a value about to be stored in the 16-bit element type: 6 from 6 up, and below 6 never
 // more than the largest element value under 6 (bf16 5.96875, fp16 5.99609375) — rounding to nearest would otherwise
 // turn (5.984, 6) into 6.0, and the backward pass, which reads the mask 0 < y < 6 from the stored output, would drop

@@ -751,12 +751,12 @@ static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0, int ktap 
   // Measured on MI355X over the R50-FPN shapes (scripts/conv_bench.py; profiles/convbench_*.log): several small
   // co-resident workgroups per CU (64-pixel tiles, 2-deep ring, 32-48 KB LDS) beat one large deeply pipelined
   // workgroup on almost every shape; only the very large-M 3x3 convs prefer the 256x128 8-wave tile.
-  static const int big_minm = getenv("TDN_T192_MINM") ? atoi(getenv("TDN_T192_MINM")) : 24000;
+  const int big_minm = getenv("TDN_T192_MINM") ? atoi(getenv("TDN_T192_MINM")) : 24000;
   if (ngemm % 256 == 0 && maxM >= big_minm) return 3;   // 192x256, 8 waves: fewest L2->LDS bytes per flop
   // few tiles and a long K loop (layer4, the top FPN levels): every CU holds at most two 4-wave workgroups and the
   // LDS-DMA stream starves (~4 B/clk per loading wave) — recruit a second wave group along K (in-workgroup split-K)
-  static const int kg_tiles = getenv("TDN_KG_TILES") ? atoi(getenv("TDN_KG_TILES")) : 512;
-  static const int kg_kmin = getenv("TDN_KG_KMIN") ? atoi(getenv("TDN_KG_KMIN")) : 2048;
+  const int kg_tiles = getenv("TDN_KG_TILES") ? atoi(getenv("TDN_KG_TILES")) : 512;
+  const int kg_kmin = getenv("TDN_KG_KMIN") ? atoi(getenv("TDN_KG_KMIN")) : 2048;
   if ((long)ceil_div(maxM, 64) * (ngemm / 64) <= kg_tiles && kgemm >= kg_kmin) return 25;
   if (ngemm % 128 == 0) {
     // A K-step costs ~1300-1500 cycles of load latency whatever the tile (scripts/trace_gemm.py), so the 128x128
@@ -765,8 +765,8 @@ static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0, int ktap 
     // chain) the 132-tile layers of layer3 (M = 8400, N = 256) run faster as 528 64x64 workgroups: whole-step A/B on
     // one box, threshold 128 -> 396 img/s, 140..200 -> 402, 268 and up -> 395 and falling.  The thresholds are
     // overridable (TDN_T128_MIN, TDN_T64_MIN, TDN_KG_TILES, TDN_KG_KMIN, TDN_T192_MINM) for such sweeps.
-    static const int t128_min = getenv("TDN_T128_MIN") ? atoi(getenv("TDN_T128_MIN")) : 200;
-    static const int t64_min = getenv("TDN_T64_MIN") ? atoi(getenv("TDN_T64_MIN")) : 300;
+    const int t128_min = getenv("TDN_T128_MIN") ? atoi(getenv("TDN_T128_MIN")) : 200;
+    const int t64_min = getenv("TDN_T64_MIN") ? atoi(getenv("TDN_T64_MIN")) : 300;
     if ((long)ceil_div(maxM, 128) * (ngemm / 128) >= t128_min) return 46;
     const long t64 = (long)ceil_div(maxM, 64) * (ngemm / 128);
     return t64 >= t64_min ? 1 : 0;

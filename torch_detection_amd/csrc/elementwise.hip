@@ -70,7 +70,8 @@ __global__ void pack_weight_kernel(const float* w, int64_t s_o, int64_t s_i, int
     if (w_dgrad) {
       const float sc = scale ? scale[co] : 1.f;
       // dgrad operand uses the bf16-rounded forward weight times the fp32 scale
-      w_dgrad[(((int64_t)ci * kh + y) * kw + x) * Cout + co] = f32_to_elem<F16>(elem_to_f32<F16>(vb) * sc);
+      w_dgrad[(((int64_t)ci * kh + y) * kw + x) * Cout + co] =
+          f32_to_elem<F16>(mul_f32_rounded(elem_to_f32<F16>(vb), sc));
     }
   }
 }
@@ -110,7 +111,7 @@ __global__ void pack_gconv_kernel(const float* w, int64_t s_o, int64_t s_i, int6
       vf = wf;
       const int co = (c & ~63) + j;   // the output channel this dgrad entry multiplies
       const float wd = w[co * s_o + (c % cpg) * s_i + y * s_h + x * s_w];
-      vd = elem_to_f32<F16>(f32_to_elem<F16>(wd)) * (scale ? scale[co] : 1.f);
+      vd = mul_f32_rounded(elem_to_f32<F16>(f32_to_elem<F16>(wd)), scale ? scale[co] : 1.f);
     }
     w_fwd[i] = f32_to_elem<F16>(vf);
     if (w_dgrad) w_dgrad[i] = f32_to_elem<F16>(vd);
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void prepare_group_kernel(const PrepGroup grp)
       bf16x4_t v;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        v[e] = f32_to_elem<F16>(elem_to_f32<F16>(f32_to_elem<F16>(tile[o4 + e][i])) * sc[e]);
+        v[e] = f32_to_elem<F16>(mul_f32_rounded(elem_to_f32<F16>(f32_to_elem<F16>(tile[o4 + e][i])), sc[e]));
       *(bf16x4_t*)(p.w_dgrad + ((long long)(i0 + i) * ntap + tap) * Cout + o0 + o4) = v;
     }
   }

@@ -26,6 +26,11 @@ from .ops import ADD_NONE, ADD_SAME, ADD_SUMPOOL2, ADD_UP2X
 # Test instrumentation: when set to a dict, the forward passes drop references to the tensors they save for
 # backward into it (keys 'seq', 'fpn') so parity tests can teacher-force the CPU schedule oracle with them.
 DEBUG_CAPTURE = None
+# Likewise for the backward: when set to a list, every dgrad launch appends
+#   ('dgrad', unit, g, in_hw, addend, addend_mode, mask_src, dx)
+# and every weight-gradient member ('wgrad', unit, x_in, g, img_hw, grads) — the operands and results of that launch,
+# so a test can recompute each launch on the CPU from the GPU's own inputs (tests/parity_util.py).
+DEBUG_BWD = None
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -389,7 +394,10 @@ def unit_dgrad(u, g, in_hw, addend=None, addend_mode=ADD_NONE, mask_src=None):
         g = _gn_dz(u, g)
     if u.groups > 1:
         return ops.gconv2d_dgrad(g, u.w_dgrad, u.groups, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
-    return ops.conv2d_dgrad(g, u.w_dgrad, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
+    dx = ops.conv2d_dgrad(g, u.w_dgrad, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
+    if DEBUG_BWD is not None:
+        DEBUG_BWD.append(('dgrad', u, g, tuple(in_hw), addend, addend_mode, mask_src, dx))
+    return dx
 
 
 # Weight-gradient kernels run on a side HIP stream: within a backward pass they depend only on tensors that
@@ -582,6 +590,8 @@ class WgradQueue(object):
         self.members.append((u, it, 1 if _t9_eligible(u, x_in) else 0))
         if self.per_layer:
             self.flush()
+        if DEBUG_BWD is not None and not dyn:
+            DEBUG_BWD.append(('wgrad', u, x_in, g, img_hw, (dw_view, dg, db)))
         if sink is not None:
             return [None] * len(u.params())
         if u.bias_and_norm:
