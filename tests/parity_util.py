@@ -184,10 +184,11 @@ def backward_in_situ(sch, rb, rf, launches, x_img):
 FWD_IN_SITU_TOL = 1e-3      # north-star figure for conv activations, per fused launch on identical inputs
                             # (measured ~3e-5: a ~2e-4 fraction of outputs round to the neighbouring bf16)
 BWD_TEACHER_TOL = 6e-2      # every parameter gradient, whole backward, identical saved activations
-                            # (measured: R18 ~1e-2, R50 ~2e-2 worst; medians ~1e-2).  Rounding noise of the bf16
-                            # activation-gradients adds up over the depth: R101 (33 blocks deeper, and only a
-                            # 2x2 map left in layer4 at the test size) measures 4.5e-2 .. 7.6e-2 -> bound 1.2e-1
-BWD_TEACHER_TOL_DEEP = 1.2e-1
+                            # (measured: R18 ~1e-2, R50 ~2e-2, R101 ~3e-2 worst; medians ~1e-2): rounding noise of the
+                            # 16-bit activation-gradients adding up over the depth.  This run checks the ROUTING of the
+                            # schedule (a missing residual / FPN / stage gradient is O(1)); the arithmetic of every
+                            # launch is bounded separately at 1e-3 on its own operands (backward_in_situ).
+BWD_TEACHER_TOL_DEEP = 6e-2  # R101: the same bound since the per-launch backward check exists (was 1.2e-1)
 FWD_END_TO_END_TOL = 2e-2   # bf16 activations vs the fp32 reference path (~1e-2 expected)
 
 

@@ -27,7 +27,7 @@ def _grads(sdb, sdf, x, cots):
     return g
 
 
-def _worker(rank, world, port, bucket_bytes, out_dir):
+def _worker(rank, world, port, bucket_bytes, out_dir, comm_dtype=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,7 +42,7 @@ def _worker(rank, world, port, bucket_bytes, out_dir):
     cots = [det_tensor(s, 910 + i, -1, 1) for i, s in enumerate(shapes)]
     g = _grads(sdb, sdf, xall[sl], cots)
     names = sorted(g)[::-1]          # any fixed "ready" order
-    red = dp.GradReducer([g[k].numel() for k in names], "cpu", bucket_bytes=bucket_bytes)
+    red = dp.GradReducer([g[k].numel() for k in names], "cpu", bucket_bytes=bucket_bytes, comm_dtype=comm_dtype)
     assert len(red.buckets) > 1
     for step in range(2):            # two steps: the reducer re-arms itself
         for i, k in enumerate(names):
@@ -72,6 +72,48 @@ def test_two_rank_average_equals_single_process(tmp_path, bucket_bytes):
     for k in full:
         assert torch.equal(r0[k], r1[k]), k                      # every rank holds the same reduced gradient
         assert rel_l2(r0[k], full[k] / world) <= 1e-5, k         # == single-process gradient / world
+
+
+def test_two_rank_bf16_wire(tmp_path):
+    """comm_dtype=bfloat16: half the bytes per bucket, every rank still ends with the same fp32 values, equal to the
+    single-process gradient / world to bfloat16 accuracy (two roundings: the operands and the sum)."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), 1 << 20, str(tmp_path), torch.bfloat16), nprocs=world, join=True)
+    import torch_detection_amd as T
+    sdb = fill_state_dict(T.ResNet(18).state_dict(), 50)
+    sdf = fill_state_dict(T.FPN([64, 128, 256, 512], 256, 5).state_dict(), 51)
+    xall = det_tensor((world, 3, 64, 64), 900, -2, 2)
+    shapes = [(1, 256, 16, 16), (1, 256, 8, 8), (1, 256, 4, 4), (1, 256, 2, 2), (1, 256, 1, 1)]
+    cots = [det_tensor(s, 910 + i, -1, 1).expand(world, -1, -1, -1).contiguous() for i, s in enumerate(shapes)]
+    torch.set_num_threads(4)
+    full = _grads(sdb, sdf, xall, cots)
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"), weights_only=True)
+    for k in full:
+        assert r0[k].dtype == torch.float32 and torch.equal(r0[k], r1[k]), k
+        assert rel_l2(r0[k], full[k] / world) <= 8e-3, k         # 2^-8 per rounding
+
+
+def test_bf16_wire_halves_the_bucket_bytes():
+    from torch_detection_amd import dp
+    n = [1 << 18] * 8                                            # 8 MiB of fp32 gradients
+    assert len(dp.GradReducer(n, "cpu", bucket_bytes=2 << 20).buckets) == 4
+    assert len(dp.GradReducer(n, "cpu", bucket_bytes=2 << 20, comm_dtype=torch.bfloat16).buckets) == 2
+
+
+def test_unproduced_slots_are_zeroed_not_reduced_again():
+    """A slot nobody wrote this step (frozen stage) must not be reduced with last step's averaged contents."""
+    from torch_detection_amd import dp
+    red = dp.GradReducer([8, 8, 8], "cpu", bucket_bytes=1 << 20)
+    for i in range(3):
+        red.views[i].fill_(float(i + 1))
+        red.mark_ready_n(0, 1, None, [i])
+    red.finish()
+    assert [float(v[0]) for v in red.views] == [1.0, 2.0, 3.0]
+    red.views[0].fill_(5.0)
+    red.mark_ready_n(0, 1, None, [0])
+    red.finish()
+    assert [float(v[0]) for v in red.views] == [5.0, 0.0, 0.0]
 
 
 def test_reducer_bucket_layout():

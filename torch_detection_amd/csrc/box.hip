@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
 constexpr int NMS_SC = 16;                       // chunks per super-chunk
 constexpr int NMS_SCROWS = NMS_SC * 64;          // 1024 rows = threads
 constexpr int NMS_DPITCH = NMS_SCROWS + 1;       // words; odd pitch: the 16 words of one row sit in 16 different banks
-constexpr int NMS_BLOCK_MAX_NBLK = 3500;         // removal bitmap + band must fit 160 KB of LDS
+constexpr int NMS_BLOCK_MAX_NBLK = 3000;         // removal bitmap + band must fit 160 KB of LDS
 
 __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned long long* __restrict__ mask,
                                                               const int* __restrict__ order, int N, int nblk,
@@ -318,6 +318,7 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
   unsigned long long* remv = sm;                                  // [nblk]
   unsigned long long* D = sm + ((nblk + 1) & ~1);                 // [NMS_SC][NMS_DPITCH]
   unsigned long long* kbits = D + NMS_SC * NMS_DPITCH;            // [NMS_SC]
+  int* ord = (int*)(kbits + NMS_SC);                              // [NMS_SCROWS] original indices of the band's boxes
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
         if (row < N && k < nch) v = src[k];
         D[k * NMS_DPITCH + tid] = v;
       }
+      ord[tid] = (row < N) ? order[row] : 0;          // no global load is left on wave 0's serial path below
     }
     __syncthreads();
     // ---- B: serial resolution of the band, wave 0 ----
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
         const unsigned long long keepbits = alive;
         if (i < N) {
           const bool k = (keepbits >> lane) & 1ull;
-          const int oi = order[i];
+          const int oi = ord[kc * 64 + lane];
           keep[oi] = k ? 1 : 0;
           if (k) kept_idx[cnt + __builtin_popcountll(keepbits & ((1ull << lane) - 1ull))] = (int64_t)oi;
         }
@@ -397,12 +399,13 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
     if (wbeg < nblk && row < N && ((kbits[tid >> 6] >> (tid & 63)) & 1ull)) {
       const unsigned long long* src = mask + (int64_t)row * nblk;
       int w = wbeg;
-      for (; w + 4 <= nblk; w += 4) {                 // 4 independent loads in flight per thread
-        const unsigned long long v0 = src[w], v1 = src[w + 1], v2 = src[w + 2], v3 = src[w + 3];
-        if (v0) atomicOr(&remv[w], v0);
-        if (v1) atomicOr(&remv[w + 1], v1);
-        if (v2) atomicOr(&remv[w + 2], v2);
-        if (v3) atomicOr(&remv[w + 3], v3);
+      for (; w + 16 <= nblk; w += 16) {               // 16 independent loads (one 128-byte stretch) in flight per thread
+        unsigned long long v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = src[w + e];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (v[e]) atomicOr(&remv[w + e], v[e]);
       }
       for (; w < nblk; ++w) {
         const unsigned long long v = src[w];
@@ -459,7 +462,7 @@ extern "C" int tdn_nms(const float* boxes, const float* scores, int N, float iou
   TDN_LAUNCH_CHECK();
   const bool one_wave = getenv("TDN_NMS_ONEWAVE") && getenv("TDN_NMS_ONEWAVE")[0] == '1';   // A/B runs
   if (nblk <= NMS_BLOCK_MAX_NBLK && !one_wave) {
-    const size_t lds = (size_t)(((nblk + 1) & ~1) + NMS_SC * NMS_DPITCH + NMS_SC) * 8;
+    const size_t lds = (size_t)(((nblk + 1) & ~1) + NMS_SC * NMS_DPITCH + NMS_SC) * 8 + NMS_SCROWS * 4;
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute((const void*)nms_scan_block_kernel,

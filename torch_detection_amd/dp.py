@@ -15,7 +15,15 @@ gradient sum.  This module supplies that exchange:
     bucket — RCCL then runs concurrently with the rest of backward;
   * xGMI is point-to-point (7 links x ~153 GB/s per GPU), so buckets are kept large (default 32 MiB: 4 buckets
     for R50-FPN's 107 MB) and RCCL is left to spread rings/channels over all links;
-  * ``finish()`` makes the compute stream wait for the comm stream and applies the 1/world average.
+  * ``finish()`` makes the compute stream wait for the comm stream and applies the 1/world average;
+  * ``comm_dtype=torch.bfloat16`` halves the bytes on the links (53.7 MB instead of 107.4 MB for R50-FPN): each bucket
+    is rounded to bfloat16 into a staging buffer on the comm stream, reduced in bfloat16, and written back to the
+    fp32 buffer in ``finish()``.  The sum then carries bfloat16 rounding (8 significant bits) — an option for
+    link-bound configurations, off by default.
+
+Semantics of the gradient views: with a reducer attached the kernels OVERWRITE ``param.grad`` every backward pass
+(beta = 0) — gradient accumulation over several backward passes, or a module applied twice in one step, is not
+supported in this mode (use the plain autograd path, which accumulates as usual).
 """
 import torch
 import torch.distributed as dist
@@ -24,10 +32,14 @@ import torch.distributed as dist
 class GradReducer(object):
     """Flat-buffer bucketed all-reduce.  ``numels``: gradient sizes in the order they become ready."""
 
-    def __init__(self, numels, device, bucket_bytes=32 << 20, group=None, average=True, dtype=torch.float32):
+    def __init__(self, numels, device, bucket_bytes=32 << 20, group=None, average=True, dtype=torch.float32,
+                 comm_dtype=None):
         self.device = torch.device(device)
         self.group = group
         self.average = average
+        if comm_dtype not in (None, torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError('comm_dtype must be None, float32, bfloat16 or float16')
+        self.comm_dtype = None if comm_dtype in (None, dtype) else comm_dtype
         self.enabled = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.enabled else 1
         # 64-element (256 B) alignment of every slot keeps kernels' float4 stores aligned
@@ -38,7 +50,9 @@ class GradReducer(object):
         self.numels = [int(n) for n in numels]
         self.flat = torch.zeros(max(off, 64), dtype=dtype, device=self.device)
         self.views = [self.flat[o:o + n] for o, n in zip(self.offsets, self.numels)]
-        esize = self.flat.element_size()
+        self.comm_buf = torch.zeros_like(self.flat, dtype=self.comm_dtype) if self.comm_dtype is not None else None
+        # bucket sizes are counted in bytes ON THE WIRE
+        esize = self.comm_buf.element_size() if self.comm_buf is not None else self.flat.element_size()
         # buckets: consecutive slots, closed when they reach bucket_bytes
         self.bucket_of, self.buckets = [], []   # buckets: [start_off, end_off, nslots]
         cur_start, cur_slots = 0, 0
@@ -58,6 +72,8 @@ class GradReducer(object):
     def reset(self):
         self._pending = [b[2] for b in self.buckets]
         self._works = []
+        self._launched = []                            # buckets reduced this step, in launch order
+        self._produced = set()                         # slots written this step (when the producers report them)
         self._producers = [{} for _ in self.buckets]   # raw stream -> stream that wrote into each bucket this step
 
     def mark_ready(self, slot, stream=None):
@@ -65,10 +81,13 @@ class GradReducer(object):
         all-reduce if complete."""
         self.mark_ready_n(self.bucket_of[slot], 1, stream)
 
-    def mark_ready_n(self, b, count, stream=None):
+    def mark_ready_n(self, b, count, stream=None, slots=None):
         """``count`` slots of bucket ``b`` have been enqueued on ``stream`` (one call per conv unit from the backward
-        schedule: a unit's weight / affine gradients are consecutive slots, normally of one bucket)."""
+        schedule: a unit's weight / affine gradients are consecutive slots, normally of one bucket).  ``slots``: which
+        ones — lets ``finish()`` zero the slots nobody wrote this step before it reduces a partly filled bucket."""
         self._pending[b] -= count
+        if slots is not None:
+            self._produced.update(slots)
         if self.use_streams and stream is not None:
             self._producers[b][stream.cuda_stream] = stream
         if self._pending[b] == 0:
@@ -82,6 +101,8 @@ class GradReducer(object):
         buf = self.flat[start:end]
         if not self.enabled:
             return
+        self._launched.append(b)
+        wire = self.comm_buf[start:end] if self.comm_buf is not None else buf
         if self.use_streams:
             # the bucket's gradients were produced on several streams (the weight-gradient kernels rotate over a
             # pool of side streams): the comm stream waits for every one of them — and for the current stream, which
@@ -91,28 +112,41 @@ class GradReducer(object):
                 ev.record(st)
                 self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if wire is not buf:
+                    wire.copy_(buf)            # fp32 -> 16-bit, round to nearest even, on the comm stream
+                w = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if wire is not buf:
+                wire.copy_(buf)
+            w = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works.append(w)
 
     def finish(self):
         """Wait for every bucket (compute stream waits on the comm stream), average, and re-arm."""
         missing = [i for i, p in enumerate(self._pending) if p > 0]
         if missing:
-            # gradients that were never produced this step (e.g. frozen stages): reduce what is there
+            # gradients that were never produced this step (e.g. frozen stages): their slots still hold the last
+            # step's already averaged values — zero them (where the producers reported their slots), then reduce
+            if self._produced:
+                for s_, (o, n) in enumerate(zip(self.offsets, self.numels)):
+                    if self.bucket_of[s_] in missing and s_ not in self._produced:
+                        self.flat[o:o + n].zero_()
             for b in missing:
                 self._launch(b)
         for w in self._works:
             w.wait()
         if self.use_streams and self.enabled:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        if self.comm_buf is not None and self.enabled:
+            for b in self._launched:           # 16-bit sums back into the fp32 gradient views
+                start, end, _ = self.buckets[b]
+                self.flat[start:end].copy_(self.comm_buf[start:end])
         if self.average and self.world > 1:
             self.flat.mul_(1.0 / self.world)
         self.reset()
 
 
-def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True, dtype=None):
+def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True, dtype=None, comm_dtype=None):
     """Wire ``GradReducer`` into HIP-path modules (given in the order their backward runs, e.g. [fpn, resnet]).
 
     Every conv unit's weight/affine gradients get a slot in the flat buffer (in backward-completion order),
@@ -136,7 +170,7 @@ def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True, dty
             numels.append(p.numel())
             owners.append((u, p))
     dev = units[0].conv.weight.device
-    red = GradReducer(numels, dev, bucket_bytes, group, average)
+    red = GradReducer(numels, dev, bucket_bytes, group, average, comm_dtype=comm_dtype)
     slot = 0
     for u in units:
         ps = u.params()
@@ -156,12 +190,12 @@ def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True, dty
 
         per_bucket = {}
         for s_ in slots:
-            per_bucket[red.bucket_of[s_]] = per_bucket.get(red.bucket_of[s_], 0) + 1
+            per_bucket.setdefault(red.bucket_of[s_], []).append(s_)
         per_bucket = tuple(per_bucket.items())
 
         def _cb(unit, stream=None, _pb=per_bucket, _red=red):
-            for b_, n_ in _pb:
-                _red.mark_ready_n(b_, n_, stream)
+            for b_, ss_ in _pb:
+                _red.mark_ready_n(b_, len(ss_), stream, ss_)
         u.on_grads = _cb
     return red
 

@@ -323,6 +323,10 @@ class gn_scope(object):
 
     def __exit__(self, *exc):
         _gn_tls.store = self.prev
+        # the per-backward dz cache (_gn_dz) must not outlive the call that filled it: a second backward through a
+        # retained graph may hand in a different g at the same address
+        for k in [k for k in self.store if isinstance(k, tuple) and len(k) == 2 and k[1] == 'dz']:
+            del self.store[k]
         return False
 
 

@@ -29,10 +29,20 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _chk_dev(t, name):
+    """Launches go to the CURRENT device's stream (``_lib.stream_ptr``): an operand living on another GPU would be
+    touched from the wrong stream / device context — refuse instead of computing garbage."""
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError("%s is on %s but the current device is cuda:%d: select the tensor's device first "
+                           "(torch.cuda.set_device / with torch.cuda.device(...))" %
+                           (name, t.device, torch.cuda.current_device()))
+
+
 def _chk_act(t, name, C=None, dtype=None):
     if t.dtype not in _CODES or not t.is_cuda or t.dim() != 4 or not t.is_contiguous():
         raise ValueError("%s must be a contiguous CUDA bfloat16/float16 NHWC tensor, got %s %s %s" %
                          (name, t.dtype, t.device, tuple(t.shape)))
+    _chk_dev(t, name)
     if dtype is not None and t.dtype != dtype:
         raise ValueError("%s is %s but the call computes in %s" % (name, t.dtype, dtype))
     if C is not None and t.shape[3] != C:
@@ -539,6 +549,7 @@ def nhwc_to_nchw_f32(x):
 def _chk_boxes(b, name):
     if b.dtype != torch.float32 or not b.is_cuda or b.dim() != 2 or b.shape[1] != 4 or not b.is_contiguous():
         raise ValueError("%s must be a contiguous CUDA float32 (K,4) tensor" % name)
+    _chk_dev(b, name)
 
 
 def anchor_grid(base_anchors, featmap_size, stride, valid_size=None):
