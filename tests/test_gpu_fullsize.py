@@ -70,7 +70,7 @@ def test_full_size_schedules_agree(T, depth, batch, dtype, monkeypatch):
     def run():
         step()
         torch.cuda.synchronize()
-        return [t.clone() for t in held["o"]], [p.grad.clone() for p in params]
+        return [t.detach().clone() for t in held["o"]], [p.grad.clone() for p in params]
 
     # default schedule, twice (run-to-run reproducibility), then without the in-workgroup split-K tiles, then plain
     o_def, g_def = run()

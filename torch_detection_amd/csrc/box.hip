@@ -302,8 +302,8 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
 //      Then keep flags and compacted indices are written (a lane's slot = kept boxes before the chunk + popcount of the
 //      kept bits below the lane, i.e. its rank in the ballot), and the kept rows are OR-ed into the removal words of
 //      the band's later chunks: lane = (word, quarter of the rows), quarters combined with two wave shuffles;
-//   C  all threads: thread t = row t of the band; a kept row streams its words past the band (contiguous in memory)
-//      and ORs them into the removal bitmap with LDS atomics.
+//   C  all threads: wave w ORs the kept rows of chunk w into the removal words past the band — lanes = consecutive
+//      words (coalesced), eight rows in flight — and adds its result to the bitmap with one LDS atomic per word.
 // The single-wave kernel above pays a global-memory round trip per chunk on its critical path (157 at N = 10k) and
 // one serial step per kept box; here the serial part touches LDS only and global latency is paid twice per 1024 boxes.
 constexpr int NMS_SC = 16;                       // chunks per super-chunk
@@ -395,21 +395,31 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
     }
     __syncthreads();
     // ---- C: kept rows of the band -> removal words past the band ----
+    // wave w takes the kept rows of chunk w, lanes take consecutive words (512-byte coalesced reads), eight rows in
+    // flight per lane; one LDS atomic per lane and word slot at the end
     const int wbeg = c0 + nch;
-    if (wbeg < nblk && row < N && ((kbits[tid >> 6] >> (tid & 63)) & 1ull)) {
-      const unsigned long long* src = mask + (int64_t)row * nblk;
-      int w = wbeg;
-      for (; w + 16 <= nblk; w += 16) {               // 16 independent loads (one 128-byte stretch) in flight per thread
-        unsigned long long v[16];
+    if (wbeg < nblk && wave < nch) {
+      const unsigned long long keepbits = kbits[wave];
+      const unsigned long long* base = mask + (int64_t)(c0 + wave) * 64 * nblk;
+      for (int wb = wbeg; wb < nblk; wb += 64) {
+        const int w = wb + lane;
+        if (w < nblk) {
+          unsigned long long acc = 0ull, kb = keepbits;
+          while (kb) {
+            unsigned long long v[8];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = src[w + e];
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (v[e]) atomicOr(&remv[w + e], v[e]);
-      }
-      for (; w < nblk; ++w) {
-        const unsigned long long v = src[w];
-        if (v) atomicOr(&remv[w], v);
+            for (int e = 0; e < 8; ++e) {
+              v[e] = 0ull;
+              if (kb) {
+                const int b = __builtin_ctzll(kb);
+                kb &= kb - 1;
+                v[e] = base[(int64_t)b * nblk + w];
+              }
+            }
+            acc |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
+          }
+          if (acc) atomicOr(&remv[w], acc);
+        }
       }
     }
     __syncthreads();
