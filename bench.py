@@ -335,7 +335,16 @@ def main():
         else:
             mode = "eager (graph capture failed%s)" % ("" if gs.captured else ": %s" % type(gs.error).__name__)
 
-    if graph is None:
+    plan = None
+    if graph is None and not use_dist:
+        # no hipGraph (refused, or --no-graph): the library's own executor — the launches of one recorded step,
+        # enqueued again by one C call per step (torch_detection_amd.graph.PreparedStep, tdn_plan_* in include/tdn.h)
+        from torch_detection_amd.graph import PreparedStep
+        ps = PreparedStep(step, params=params, repack=False)
+        if ps.prepared:
+            plan = ps
+            mode = "launch plan replay (libtdn executor: %d launches, %d events per step, one C call)" % ps.stats()[:2]
+    if graph is None and plan is None:
         # eager launches: run autograd's backward on this thread — the hand-off to the engine's device thread costs
         # ~1.5 ms of the ~7.4 ms it takes to enqueue a step (scripts/host_profile.py), and the step is host-bound
         torch.autograd.set_multithreading_enabled(False)
@@ -344,12 +353,14 @@ def main():
     def run_step():
         if graph is not None:
             graph()
+        elif plan is not None:
+            plan()
         else:
             step()
 
     for _ in range(args.warmup):
         run_step()
-    timer = None if (args.no_kernel_timer or graph is not None) else KernelTimer(ops, DOM)
+    timer = None if (args.no_kernel_timer or graph is not None or plan is not None) else KernelTimer(ops, DOM)
     sync()
     t0 = time.perf_counter()
     if timer is not None:
@@ -364,7 +375,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
     timed_in = "the timed region"
-    if graph is not None and not args.no_kernel_timer:
+    if (graph is not None or plan is not None) and not args.no_kernel_timer:
         # HIP events cannot be read back from inside a replayed graph: time the dominant launch in eager steps of
         # the same process / tensors right after the timed region (same kernel, same stream, full-step context)
         timer = KernelTimer(ops, DOM)

@@ -269,6 +269,27 @@ int tdn_nchw_f32_to_nhwc(const float* src, int64_t s_n, int64_t s_c, int64_t s_h
 int tdn_nhwc_to_nchw_f32(const void* src, int N, int C, int H, int W, float* dst, int dtype,
                          void* stream);
 
+/* ---- prepared launch lists -----------------------------------------------------------------------------------------
+ * One C call that enqueues a whole recorded step (the launches behind ResNet.forward, models/backbone/resnet.py:253-268,
+ * FPN.forward, models/necks/fpn.py:88-125, and their backward) for callers that cannot capture a hipGraph.
+ *   tdn_plan_begin()            start recording: every launch the library makes from now on is also kept (stream,
+ *                               kernel, arguments by value); one recording at a time, process-wide
+ *   tdn_plan_event_record(s)    the host recorded an event on stream s here -> plan-local event id (-1: not recording)
+ *   tdn_plan_stream_wait(s, id) the host made stream s wait for that event here
+ *   tdn_plan_end()              stop recording -> plan handle (NULL on error)
+ *   tdn_plan_run(plan)          enqueue everything again, same streams, same order, same dependencies; no sync
+ *   tdn_plan_stats(plan, out)   out[3] = {launches, event records, stream waits}
+ *   tdn_plan_free(plan)
+ * Pointers held by the recorded arguments must still refer to the same buffers when the plan runs (the host keeps the
+ * recorded step's tensors alive in a private pool, like a captured graph does). */
+int tdn_plan_begin(void);
+void* tdn_plan_end(void);
+int tdn_plan_event_record(void* stream);
+int tdn_plan_stream_wait(void* stream, int event_id);
+int tdn_plan_run(void* plan);
+int tdn_plan_stats(void* plan, int32_t* out3);
+int tdn_plan_free(void* plan);
+
 /* ---- box ops (absent from the reference: core/__init__.py is empty; semantics = SURVEY Appendix B,
  *      conventions pinned by datasets/utils/bbox.py:39,375-377 and dataset_transforms.py:120-131) ---- */
 

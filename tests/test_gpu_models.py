@@ -454,6 +454,56 @@ def test_graph_replay_sees_weight_update(T, how):
     assert all(torch.equal(p.grad, g) for p, g in zip(params, got_g))
 
 
+def test_prepared_step_matches_eager(T):
+    """PreparedStep (the launch plan of libtdn: one C call enqueues the recorded forward + backward, side streams and
+    their event dependencies included) == the eager step, bit for bit, repeatedly; it sees weight updates because the
+    fold / pack launches are part of the plan; and a step that does GPU work outside the library is refused."""
+    m, neck, x, params = _small_net(T)
+    with torch.no_grad():
+        outs = neck(m(x))
+    cots = [det_tensor(tuple(o.shape), 20 + i, -1, 1).cuda().to(o.dtype) for i, o in enumerate(outs)]
+    del outs
+    held = {}
+
+    def step():
+        for p in params:
+            p.grad = None
+        o = neck(m(x))
+        torch.autograd.backward(o, cots)
+        held["o"] = o
+
+    ps = T.PreparedStep(step, params=params, modules=(m, neck))
+    assert ps.prepared, ps.error
+    nl, ne, nw = ps.stats()
+    assert nl > 60 and ne > 0 and nw >= ne
+    ps()
+    ps()
+    torch.cuda.synchronize()
+    got_o = [t.detach().clone() for t in held["o"]]
+    got_g = [p.grad.clone() for p in params]
+    with torch.no_grad():
+        for i, p in enumerate(params):
+            p.mul_(1.0 + 0.01 * ((i % 3) - 1))
+    ps()
+    torch.cuda.synchronize()
+    new_o = [t.detach().clone() for t in held["o"]]
+    new_g = [p.grad.clone() for p in params]
+    assert not all(torch.equal(a, b) for a, b in zip(new_o, got_o))
+    ps.close()
+    held.clear()
+    step()                                 # eager, on the updated weights
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(held["o"], new_o))
+    assert all(torch.equal(p.grad, g) for p, g in zip(params, new_g))
+
+    def impure():
+        step()
+        params[0].grad.mul_(2.0)           # a PyTorch kernel the plan cannot contain
+
+    bad = T.PreparedStep(impure, params=params, modules=(m, neck), verbose=False)
+    assert not bad.prepared and "outside the library" in str(bad.error)
+
+
 @pytest.mark.parametrize("depth", [18, 50])
 def test_branch_streams_change_nothing(T, depth, monkeypatch):
     """functional.branch moves independent launches (downsample conv / dgrad, coarse FPN output convs, lateral dgrads)

@@ -17,7 +17,7 @@ from .backbone import (BasicBlock, Bottleneck, ResNet, ResNeXt, ResNeXtBasicBloc
                        ResNeXtBottleneck)
 from .necks import FPN, PAFPN  # noqa: F401
 from .staging import ImageTransforms, StagedImages  # noqa: F401
-from .graph import GraphedStep  # noqa: F401
+from .graph import GraphedStep, PreparedStep  # noqa: F401
 from .functional import invalidate_packed  # noqa: F401
 from .box import (AnchorGenerator, anchor_pyramid, bbox_denormalize, bbox_normalize, bbox_overlaps, nms,  # noqa: F401
                   nms_mask)

@@ -143,6 +143,13 @@ SIGNATURES = {
     "tdn_collate_images": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32),
                                    ctypes.POINTER(ctypes.c_uint8), c_int, c_int, ctypes.POINTER(c_float),
                                    ctypes.POINTER(c_float), c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "tdn_plan_begin": (c_int, []),
+    "tdn_plan_end": (c_void_p, []),
+    "tdn_plan_event_record": (c_int, [c_void_p]),
+    "tdn_plan_stream_wait": (c_int, [c_void_p, c_int]),
+    "tdn_plan_run": (c_int, [c_void_p]),
+    "tdn_plan_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "tdn_plan_free": (c_int, [c_void_p]),
     "tdn_conv2d_plan": (c_int, [c_int] * 9 + [ctypes.POINTER(ctypes.c_int32)]),
     "tdn_debug_trace": (c_int, [c_void_p, ctypes.c_longlong]),
 }

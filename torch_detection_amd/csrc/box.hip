@@ -38,7 +38,7 @@ extern "C" int tdn_anchor_grid(const float* base_anchors, int A, int featH, int 
   TDN_CHECK(base_anchors && anchors, "tdn_anchor_grid: NULL pointer");
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(anchor_grid_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, base_anchors, A, featH,
+  TDN_LAUNCH(anchor_grid_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, base_anchors, A, featH,
                      featW, stride, valid_h, valid_w, anchors, valid);
   TDN_LAUNCH_CHECK();
   return 0;
@@ -101,7 +101,7 @@ extern "C" int tdn_anchor_pyramid(const tdn_anchor_level* levels, int nlevels, f
   TDN_CHECK(anchors != nullptr, "tdn_anchor_pyramid: NULL output");
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(anchor_pyramid_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, L, anchors, valid);
+  TDN_LAUNCH(anchor_pyramid_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, L, anchors, valid);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -167,7 +167,7 @@ extern "C" int tdn_bbox_iou_pairwise(const float* a, int N, const float* b, int 
   const int64_t total = (int64_t)N * ((M + 3) / 4);
   int64_t grid = (total + 255) / 256;
   if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(iou_pairwise_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a, N, b, M, iou);
+  TDN_LAUNCH(iou_pairwise_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a, N, b, M, iou);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -330,13 +330,17 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
     const int nch = min(NMS_SC, nblk - c0);
     const int row = c0 * 64 + tid;
     // ---- A: diagonal band -> LDS ----
+    // 16 lanes read the 16 words of one row (128 contiguous bytes): a wave instruction covers 4 rows = 4-8 cache
+    // lines, not 64 rows of one word each
     {
-      const unsigned long long* src = mask + (int64_t)row * nblk + c0;
-#pragma unroll
-      for (int k = 0; k < NMS_SC; ++k) {
+      const int k = tid & 15;
+#pragma unroll 4
+      for (int j = 0; j < NMS_SC; ++j) {
+        const int r = (tid >> 4) + 64 * j;              // row of the band
+        const int grow = c0 * 64 + r;
         unsigned long long v = 0ull;
-        if (row < N && k < nch) v = src[k];
-        D[k * NMS_DPITCH + tid] = v;
+        if (grow < N && k < nch) v = mask[(int64_t)grow * nblk + c0 + k];
+        D[k * NMS_DPITCH + r] = v;
       }
       ord[tid] = (row < N) ? order[row] : 0;          // no global load is left on wave 0's serial path below
     }
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
     }
     __syncthreads();
     // ---- C: kept rows of the band -> removal words past the band ----
-    // wave w takes the kept rows of chunk w, lanes take consecutive words (512-byte coalesced reads), eight rows in
+    // wave w takes the kept rows of chunk w, lanes take consecutive words (512-byte coalesced reads), sixteen rows in
     // flight per lane; one LDS atomic per lane and word slot at the end
     const int wbeg = c0 + nch;
     if (wbeg < nblk && wave < nch) {
@@ -406,9 +410,9 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
         if (w < nblk) {
           unsigned long long acc = 0ull, kb = keepbits;
           while (kb) {
-            unsigned long long v[8];
+            unsigned long long v[16];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 16; ++e) {
               v[e] = 0ull;
               if (kb) {
                 const int b = __builtin_ctzll(kb);
@@ -416,7 +420,8 @@ __global__ __launch_bounds__(1024) void nms_scan_block_kernel(const unsigned lon
                 v[e] = base[(int64_t)b * nblk + w];
               }
             }
-            acc |= ((v[0] | v[1]) | (v[2] | v[3])) | ((v[4] | v[5]) | (v[6] | v[7]));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc |= v[e];
           }
           if (acc) atomicOr(&remv[w], acc);
         }
@@ -445,7 +450,7 @@ extern "C" int tdn_nms(const float* boxes, const float* scores, int N, float iou
   TDN_CHECK(N >= 0 && N <= 64 * 8000, "tdn_nms: N=%d out of range (0..512000)", N);
   TDN_CHECK(num_kept != nullptr, "tdn_nms: NULL num_kept");
   if (N == 0) {
-    (void)hipMemsetAsync(num_kept, 0, sizeof(int32_t), st);
+    TDN_MEMSET_ASYNC(num_kept, 0, sizeof(int32_t), st);
     return 0;
   }
   TDN_CHECK(boxes && scores && keep && kept_idx && workspace, "tdn_nms: NULL pointer");
@@ -457,18 +462,18 @@ extern "C" int tdn_nms(const float* boxes, const float* scores, int N, float iou
   int* order = (int*)ws; ws += align256((int64_t)N * 4);
   float* sboxes = (float*)ws; ws += align256((int64_t)N * 16);
   unsigned long long* mask = (unsigned long long*)ws;
-  (void)hipMemsetAsync(rank, 0, (size_t)N * 4, st);
+  TDN_MEMSET_ASYNC(rank, 0, (size_t)N * 4, st);
   const int nb = (N + 255) / 256;
   int jsplit = 1024 / nb;  // aim for ~1024 blocks
   if (jsplit < 1) jsplit = 1;
   if (jsplit > (N + 1023) / 1024) jsplit = (N + 1023) / 1024;
   const int jchunk = ((N + jsplit - 1) / jsplit + 1023) / 1024 * 1024;
   jsplit = (N + jchunk - 1) / jchunk;
-  hipLaunchKernelGGL(nms_rank_kernel, dim3(nb, jsplit), dim3(256), 0, st, scores, N, jchunk, rank);
+  TDN_LAUNCH(nms_rank_kernel, dim3(nb, jsplit), dim3(256), 0, st, scores, N, jchunk, rank);
   TDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_scatter_kernel, dim3(nb), dim3(256), 0, st, boxes, rank, N, order, sboxes);
+  TDN_LAUNCH(nms_scatter_kernel, dim3(nb), dim3(256), 0, st, boxes, rank, N, order, sboxes);
   TDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, st, sboxes, N, iou_thr, nblk, mask);
+  TDN_LAUNCH(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, st, sboxes, N, iou_thr, nblk, mask);
   TDN_LAUNCH_CHECK();
   const bool one_wave = getenv("TDN_NMS_ONEWAVE") && getenv("TDN_NMS_ONEWAVE")[0] == '1';   // A/B runs
   if (nblk <= NMS_BLOCK_MAX_NBLK && !one_wave) {
@@ -480,10 +485,10 @@ extern "C" int tdn_nms(const float* boxes, const float* scores, int N, float iou
       TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(nms scan LDS) failed: %s", hipGetErrorString(e));
       attr_set = true;
     }
-    hipLaunchKernelGGL(nms_scan_block_kernel, dim3(1), dim3(1024), lds, st, mask, order, N, nblk, keep, kept_idx,
+    TDN_LAUNCH(nms_scan_block_kernel, dim3(1), dim3(1024), lds, st, mask, order, N, nblk, keep, kept_idx,
                        num_kept);
   } else {
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)nblk * 8, st, mask, order, N, nblk, keep, kept_idx,
+    TDN_LAUNCH(nms_scan_kernel, dim3(1), dim3(64), (size_t)nblk * 8, st, mask, order, N, nblk, keep, kept_idx,
                        num_kept);
   }
   TDN_LAUNCH_CHECK();
@@ -521,7 +526,7 @@ extern "C" int tdn_bbox_normalize(float* bbox, int64_t rows, const float* means4
   const f32x4_t m = {means4[0], means4[1], means4[2], means4[3]}, s = {stds4[0], stds4[1], stds4[2], stds4[3]};
   int64_t grid = (rows + 255) / 256;
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(bbox_normalize_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, bbox, rows, m, s);
+  TDN_LAUNCH(bbox_normalize_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, bbox, rows, m, s);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -535,7 +540,7 @@ extern "C" int tdn_bbox_denormalize(const float* bbox, float* out, int64_t rows,
   const f32x4_t m = {means4[0], means4[1], means4[2], means4[3]}, s = {stds4[0], stds4[1], stds4[2], stds4[3]};
   int64_t grid = (n4 + 255) / 256;
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(bbox_denormalize_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, bbox, out, n4, m, s);
+  TDN_LAUNCH(bbox_denormalize_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, bbox, out, n4, m, s);
   TDN_LAUNCH_CHECK();
   return 0;
 }

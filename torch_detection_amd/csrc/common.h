@@ -35,13 +35,36 @@ void tdn_set_error(const char* fmt, ...);
     }                                                                   \
   } while (0)
 
+// ---- launch recorder (plan.hip) ---------------------------------------------------------------
+// Every kernel launch of the library goes through TDN_LAUNCH.  Normally that is just the launch.  While a plan is
+// being recorded (tdn_plan_begin ... tdn_plan_end) the launch is ALSO kept, with all its arguments by value, as a
+// closure that tdn_plan_run can issue again on the same stream: a prepared step is then one C call that enqueues the
+// whole launch list, instead of ~230 trips through the host-side operator layer.
+#include <functional>
+bool tdn_plan_recording();
+void tdn_plan_push(hipStream_t stream, std::function<void(hipStream_t)> fn);
+#define TDN_LAUNCH(kernel, grid, block, lds, stream, ...)                                                     \
+  do {                                                                                                        \
+    hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)(stream), __VA_ARGS__);                         \
+    if (tdn_plan_recording())                                                                                 \
+      tdn_plan_push((hipStream_t)(stream), [=](hipStream_t s__) {                                             \
+        hipLaunchKernelGGL(kernel, grid, block, lds, s__, __VA_ARGS__);                                       \
+      });                                                                                                     \
+  } while (0)
+#define TDN_MEMSET_ASYNC(ptr, value, bytes, stream)                                                           \
+  do {                                                                                                        \
+    (void)hipMemsetAsync(ptr, value, bytes, (hipStream_t)(stream));                                           \
+    if (tdn_plan_recording())                                                                                 \
+      tdn_plan_push((hipStream_t)(stream), [=](hipStream_t s__) { (void)hipMemsetAsync(ptr, value, bytes, s__); }); \
+  } while (0)
+
 #define TDN_CHECK_DTYPE(dtype) \
   TDN_CHECK((dtype) == TDN_BF16 || (dtype) == TDN_F16, "dtype %d is neither TDN_BF16 nor TDN_F16", (int)(dtype))
 // launch kernel<F16> chosen by the run-time dtype code
 #define TDN_LAUNCH_T(kernel, dtype, grid, block, stream, ...)                                  \
   do {                                                                                         \
-    if ((dtype) == TDN_F16) hipLaunchKernelGGL(kernel<true>, grid, block, 0, stream, __VA_ARGS__);  \
-    else hipLaunchKernelGGL(kernel<false>, grid, block, 0, stream, __VA_ARGS__);                \
+    if ((dtype) == TDN_F16) TDN_LAUNCH(kernel<true>, grid, block, 0, stream, __VA_ARGS__);  \
+    else TDN_LAUNCH(kernel<false>, grid, block, 0, stream, __VA_ARGS__);                \
   } while (0)
 
 // ---- small device helpers -------------------------------------------------------------

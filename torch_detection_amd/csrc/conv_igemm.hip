@@ -816,7 +816,7 @@ static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
     p.trace = g_trace_buf;
   }
   dim3 grid(p.nwg_pad, p.ncls, 1), block(WM * WN * KG * 64, 1, 1);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG, F16>), grid, block, lds, stream, p);
+  TDN_LAUNCH((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG, F16>), grid, block, lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
 }

@@ -1036,7 +1036,7 @@ static int launch_tap_t(const WgGroup& grp, int nblocks, hipStream_t stream) {
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_group_kernel<BMW, BNW, WM, WN, NST, F16>), dim3(nblocks), dim3(WM * WN * 64), lds,
+  TDN_LAUNCH((conv_wgrad_group_kernel<BMW, BNW, WM, WN, NST, F16>), dim3(nblocks), dim3(WM * WN * 64), lds,
                      stream, grp);
   TDN_LAUNCH_CHECK();
   return 0;
@@ -1068,7 +1068,7 @@ static int launch_t9(const WgGroup& grp, int nblocks, hipStream_t stream) {
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad9_group_kernel<F16>), dim3(nblocks), dim3(512), lds, stream, grp);
+  TDN_LAUNCH((conv_wgrad9_group_kernel<F16>), dim3(nblocks), dim3(512), lds, stream, grp);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -1180,9 +1180,9 @@ extern "C" int tdn_wgrad_group(const tdn_wgrad_item* items, int n, void* workspa
       blk += g.direct ? ceil_div(g.Cout, 256) : g.Cout;
     }
     if (dtype == TDN_F16)
-      hipLaunchKernelGGL(wgrad_finalize_group_kernel<true>, dim3(blk), dim3(256), 0, stream, fg);
+      TDN_LAUNCH(wgrad_finalize_group_kernel<true>, dim3(blk), dim3(256), 0, stream, fg);
     else
-      hipLaunchKernelGGL(wgrad_finalize_group_kernel<false>, dim3(blk), dim3(256), 0, stream, fg);
+      TDN_LAUNCH(wgrad_finalize_group_kernel<false>, dim3(blk), dim3(256), 0, stream, fg);
     TDN_LAUNCH_CHECK();
   }
   return 0;

@@ -45,7 +45,7 @@ extern "C" int tdn_bn_fold(const float* gamma, const float* beta, const float* m
                            float eps, int C, float* scale, float* shift, float* invstd, void* stream) {
   TDN_CHECK(gamma && beta && mean && var && scale && shift && invstd, "tdn_bn_fold: NULL pointer");
   TDN_CHECK(C > 0, "tdn_bn_fold: C=%d", C);
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+  TDN_LAUNCH(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
                      mean, var, eps, C, scale, shift, invstd);
   TDN_LAUNCH_CHECK();
   return 0;
@@ -464,7 +464,7 @@ extern "C" int tdn_subsample2_fwd(const void* x, void* y, int N, int H, int W, i
   TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "tdn_subsample2_fwd: bad arguments");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  hipLaunchKernelGGL(subsample_fwd_kernel, dim3(grid_for((int64_t)N * Ho * Wo * (C / 8), 256)), dim3(256), 0,
+  TDN_LAUNCH(subsample_fwd_kernel, dim3(grid_for((int64_t)N * Ho * Wo * (C / 8), 256)), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo);
   TDN_LAUNCH_CHECK();
   return 0;
@@ -725,7 +725,7 @@ extern "C" int tdn_channel_affine_bwd(const void* g, const void* x, const float*
   TDN_LAUNCH_T(channel_affine_bwd_kernel, dtype, dim3(chunks), dim3(256), (hipStream_t)stream, (const bf16_t*)g,
                (const bf16_t*)x, scale, mean, (bf16_t*)dx, (float*)workspace, npix, C);
   TDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(channel_affine_bwd_reduce_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
+  TDN_LAUNCH(channel_affine_bwd_reduce_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, chunks, C, invstd, dgamma, dbeta, beta);
   TDN_LAUNCH_CHECK();
   return 0;
@@ -890,16 +890,16 @@ extern "C" int tdn_collate_images(const void* const* imgs, const int32_t* hw, co
   hipStream_t st = (hipStream_t)stream;
   if (out_kind == 0) {
     const int64_t total = (int64_t)N * Hb * Wb;
-    if (src_kind) hipLaunchKernelGGL(collate_nchw_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, st, a, (float*)out);
-    else hipLaunchKernelGGL(collate_nchw_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, st, a, (float*)out);
+    if (src_kind) TDN_LAUNCH(collate_nchw_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, st, a, (float*)out);
+    else TDN_LAUNCH(collate_nchw_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, st, a, (float*)out);
   } else {
     const int64_t total = (int64_t)N * (Hb + 6) * (Wb + 8);
     const dim3 g(grid_for(total, 256)), b(256);
     const bool f16 = dtype == TDN_F16;
-    if (src_kind && f16) hipLaunchKernelGGL((collate_staged_kernel<true, true>), g, b, 0, st, a, (bf16_t*)out);
-    else if (src_kind) hipLaunchKernelGGL((collate_staged_kernel<true, false>), g, b, 0, st, a, (bf16_t*)out);
-    else if (f16) hipLaunchKernelGGL((collate_staged_kernel<false, true>), g, b, 0, st, a, (bf16_t*)out);
-    else hipLaunchKernelGGL((collate_staged_kernel<false, false>), g, b, 0, st, a, (bf16_t*)out);
+    if (src_kind && f16) TDN_LAUNCH((collate_staged_kernel<true, true>), g, b, 0, st, a, (bf16_t*)out);
+    else if (src_kind) TDN_LAUNCH((collate_staged_kernel<true, false>), g, b, 0, st, a, (bf16_t*)out);
+    else if (f16) TDN_LAUNCH((collate_staged_kernel<false, true>), g, b, 0, st, a, (bf16_t*)out);
+    else TDN_LAUNCH((collate_staged_kernel<false, false>), g, b, 0, st, a, (bf16_t*)out);
   }
   TDN_LAUNCH_CHECK();
   return 0;

@@ -380,11 +380,11 @@ extern "C" int tdn_gn_fwd(const void* z, const float* gamma, const float* beta, 
   hipStream_t st = (hipStream_t)stream;
   const dim3 gp(ge.chunks, N);
   if (dtype == TDN_F16)
-    hipLaunchKernelGGL((gn_partial_kernel<0, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
+    TDN_LAUNCH((gn_partial_kernel<0, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
   else
-    hipLaunchKernelGGL((gn_partial_kernel<0, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
+    TDN_LAUNCH((gn_partial_kernel<0, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
   const int CB = ge.cpg > 32 ? ge.cpg : 32;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(ceil_div(C, CB), N), dim3(kThreads), 0, st, part, ge, CB, gamma, beta, eps,
+  TDN_LAUNCH(gn_stats_kernel, dim3(ceil_div(C, CB), N), dim3(kThreads), 0, st, part, ge, CB, gamma, beta, eps,
                      stats, coef);
   const int64_t total = (int64_t)N * ge.HW * ge.C8;
   int grid = (int)((total + kThreads - 1) / kThreads);
@@ -409,11 +409,11 @@ extern "C" int tdn_gn_bwd(const void* g, const void* z, const float* stats, cons
   hipStream_t st = (hipStream_t)stream;
   const dim3 gp(ge.chunks, N);
   if (dtype == TDN_F16)
-    hipLaunchKernelGGL((gn_partial_kernel<1, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
+    TDN_LAUNCH((gn_partial_kernel<1, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
   else
-    hipLaunchKernelGGL((gn_partial_kernel<1, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
+    TDN_LAUNCH((gn_partial_kernel<1, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
   const int CB = ge.cpg > 32 ? ge.cpg : 32;
-  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(ceil_div(C, CB)), dim3(kThreads), 0, st, part, ge, CB, gamma, stats,
+  TDN_LAUNCH(gn_bwd_coef_kernel, dim3(ceil_div(C, CB)), dim3(kThreads), 0, st, part, ge, CB, gamma, stats,
                      coef3, dgamma, dbeta, acc);
   const int64_t total = (int64_t)N * ge.HW * ge.C8;
   int grid = (int)((total + kThreads - 1) / kThreads);
@@ -448,10 +448,10 @@ extern "C" int tdn_bn_train_fwd(const void* z, const float* gamma, const float* 
   hipStream_t st = (hipStream_t)stream;
   const dim3 gp(ge.chunks, N);
   if (dtype == TDN_F16)
-    hipLaunchKernelGGL((gn_partial_kernel<0, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
+    TDN_LAUNCH((gn_partial_kernel<0, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
   else
-    hipLaunchKernelGGL((gn_partial_kernel<0, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(C, 32)), dim3(kThreads), 0, st, part, ge, gamma, beta, eps,
+    TDN_LAUNCH((gn_partial_kernel<0, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, nullptr, nullptr, ge, part);
+  TDN_LAUNCH(bn_stats_kernel, dim3(ceil_div(C, 32)), dim3(kThreads), 0, st, part, ge, gamma, beta, eps,
                      momentum, running_mean, running_var, stats, coef);
   const int64_t total = (int64_t)N * ge.HW * ge.C8;
   int grid = (int)((total + kThreads - 1) / kThreads);
@@ -476,10 +476,10 @@ extern "C" int tdn_bn_train_bwd(const void* g, const void* z, const float* stats
   hipStream_t st = (hipStream_t)stream;
   const dim3 gp(ge.chunks, N);
   if (dtype == TDN_F16)
-    hipLaunchKernelGGL((gn_partial_kernel<1, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
+    TDN_LAUNCH((gn_partial_kernel<1, true>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
   else
-    hipLaunchKernelGGL((gn_partial_kernel<1, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(ceil_div(C, 32)), dim3(kThreads), 0, st, part, ge, gamma, stats,
+    TDN_LAUNCH((gn_partial_kernel<1, false>), gp, dim3(kThreads), 0, st, (const bf16_t*)z, (const bf16_t*)g, stats, ge, part);
+  TDN_LAUNCH(bn_bwd_coef_kernel, dim3(ceil_div(C, 32)), dim3(kThreads), 0, st, part, ge, gamma, stats,
                      coef3, dgamma, dbeta, acc);
   const int64_t total = (int64_t)N * ge.HW * ge.C8;
   int grid = (int)((total + kThreads - 1) / kThreads);

@@ -20,7 +20,7 @@ import threading
 import torch
 import torch.nn as nn
 
-from . import _lib, ops
+from . import _lib, ops, streams
 from .ops import ADD_NONE, ADD_SAME, ADD_SUMPOOL2, ADD_UP2X
 
 # Test instrumentation: when set to a dict, the forward passes drop references to the tensors they save for
@@ -446,12 +446,12 @@ def join_side_stream(device):
     if pool:
         cur = torch.cuda.current_stream(device)
         for st in pool:
-            cur.wait_stream(st)
+            streams.wait_stream(cur, st)
     used = _branch_used.pop(key, None)
     if used:
         cur = torch.cuda.current_stream(device)
         for st in used:
-            cur.wait_stream(st)
+            streams.wait_stream(cur, st)
     _side_refs.pop(key, None)
 
 
@@ -487,9 +487,7 @@ class branch(object):
 
     def __enter__(self):
         if self.side is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self.side.wait_event(ev)
+            streams.wait_stream(self.side, torch.cuda.current_stream(self.device))
             _side_refs.setdefault(self.key, []).extend(self.keep)
             _branch_used.setdefault(self.key, set()).add(self.side)
             self.prev = _lib.set_stream_override(self.side.cuda_stream)
@@ -498,13 +496,12 @@ class branch(object):
     def __exit__(self, *exc):
         if self.side is not None:
             _lib.set_stream_override(self.prev)
-            self.done = torch.cuda.Event()
-            self.done.record(self.side)
+            self.done = streams.record(self.side)
         return False
 
     def join(self):
         if self.side is not None:
-            torch.cuda.current_stream(self.device).wait_event(self.done)
+            streams.wait(torch.cuda.current_stream(self.device), self.done)
 
 
 def join_branches(device):
@@ -515,7 +512,7 @@ def join_branches(device):
     if used:
         cur = torch.cuda.current_stream(device)
         for st in used:
-            cur.wait_stream(st)
+            streams.wait_stream(cur, st)
     _side_refs.pop(key, None)
 
 
@@ -626,9 +623,8 @@ class WgradQueue(object):
             prev = None
             if side is not None:
                 if ev is None:
-                    ev = torch.cuda.Event()
-                    ev.record()           # every g recorded so far is ready on the main stream
-                side.wait_event(ev)
+                    ev = streams.record(torch.cuda.current_stream(dev))   # every g recorded so far is ready there
+                streams.wait(side, ev)
                 prev = _lib.set_stream_override(side.cuda_stream)
             try:
                 ops.wgrad_group([it for _, it in grp], grp[0][0].dtype, dev)
@@ -883,10 +879,9 @@ def _blocks_fwd_split(blocks, cur):
         res = new(out.shape[1], out.shape[2], out.shape[3]) if b.ud is not None else None
         bufs.append((h1, h2, out, res))
         x = out
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
+    ev = streams.record(torch.cuda.current_stream(dev))
     for i in range(ways):
-        pool[i].wait_event(ev)
+        streams.wait(pool[i], ev)
     # Launch order: block by block, alternating between the chains.  A captured hipGraph is replayed by the host in
     # capture order, node by node (rocprofv3 timeline: with one chain captured after the other, the second chain's
     # first kernel was submitted only when the first chain had almost run to its end) — so the chains are interleaved
@@ -903,7 +898,7 @@ def _blocks_fwd_split(blocks, cur):
                 _lib.set_stream_override(prev)
     main = torch.cuda.current_stream(dev)
     for i in range(ways):
-        main.wait_stream(pool[i])
+        streams.wait_stream(main, pool[i])
     saved, x = [], cur
     for (h1, h2, out, res) in bufs:
         saved.append((x, h1, h2, out))
