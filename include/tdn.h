@@ -266,6 +266,9 @@ int tdn_channel_affine_bwd(const void* g, const void* x, const float* scale, con
 
 int tdn_nchw_f32_to_nhwc(const float* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w,
                          int N, int C, int H, int W, void* dst, int dtype, void* stream);
+/* 16-bit source (bf16 or fp16 bits, element strides of the logical NCHW tensor) -> contiguous NHWC of the same type */
+int tdn_nchw16_to_nhwc(const void* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N, int C, int H,
+                       int W, void* dst, void* stream);
 int tdn_nhwc_to_nchw_f32(const void* src, int N, int C, int H, int W, float* dst, int dtype,
                          void* stream);
 

@@ -269,6 +269,12 @@ def test_layout_converters(ops):
     # zero-copy for permuted bf16 NHWC
     z = y.permute(0, 3, 1, 2)
     assert ops.to_nhwc_bf16(z).data_ptr() == y.data_ptr()
+    # 16-bit NCHW-contiguous (and sliced) sources go through the library's own transpose (tdn_nchw16_to_nhwc)
+    for dt in (torch.bfloat16, torch.float16):
+        src = xg.to(dt)                                  # plain NCHW strides
+        assert torch.equal(ops.to_nhwc_bf16(src, dt), src.permute(0, 2, 3, 1).contiguous())
+        sl = src[:, 3:67, 1:8, 2:11]                     # non-contiguous view
+        assert torch.equal(ops.to_nhwc_bf16(sl, dt), sl.permute(0, 2, 3, 1).contiguous())
 
 
 def test_pack_and_fold(ops):

@@ -115,6 +115,8 @@ SIGNATURES = {
     "tdn_channel_affine_bwd": (c_int, [c_void_p] * 8 + [c_float, c_i64, c_int, c_void_p, c_i64, c_int, c_void_p]),
     "tdn_nchw_f32_to_nhwc": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p,
                                      c_int, c_void_p]),
+    "tdn_nchw16_to_nhwc": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p,
+                                   c_void_p]),
     "tdn_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "tdn_anchor_grid": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tdn_anchor_pyramid": (c_int, [_AL, c_int, c_void_p, c_void_p, c_void_p]),

@@ -774,6 +774,49 @@ extern "C" int tdn_nchw_f32_to_nhwc(const float* src, int64_t s_n, int64_t s_c, 
   return 0;
 }
 
+// The same transpose for a source that already holds 16-bit elements (a cotangent or feature map handed in as a
+// plain NCHW-contiguous tensor): a pure move of 2-byte values, dtype-agnostic.  Keeps the whole boundary conversion
+// inside the library, so a recorded launch plan (plan.hip) contains it.
+__global__ void nchw16_to_nhwc_kernel(const unsigned short* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w,
+                                      int N, int C, int H, int W, unsigned short* dst) {
+  __shared__ unsigned short t[32][34];
+  const int HW = H * W;
+  const int tiles_p = ceil_div(HW, 32), tiles_c = ceil_div(C, 32);
+  const int64_t ntiles = (int64_t)N * tiles_p * tiles_c;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tc = (int)(tile % tiles_c);
+    int64_t r = tile / tiles_c;
+    const int tp = (int)(r % tiles_p);
+    const int n = (int)(r / tiles_p);
+    for (int k = ty; k < 32; k += 8) {
+      const int c = tc * 32 + k, pix = tp * 32 + tx;
+      unsigned short v = 0;
+      if (c < C && pix < HW) {
+        const int h = pix / W, w = pix - h * W;
+        v = src[n * s_n + c * s_c + h * s_h + w * s_w];
+      }
+      t[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      const int pix = tp * 32 + k, c = tc * 32 + tx;
+      if (c < C && pix < HW) dst[((int64_t)n * HW + pix) * C + c] = t[tx][k];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int tdn_nchw16_to_nhwc(const void* src, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, int N, int C,
+                                  int H, int W, void* dst, void* stream) {
+  TDN_CHECK(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "tdn_nchw16_to_nhwc: bad arguments");
+  const int64_t ntiles = (int64_t)N * ceil_div(H * W, 32) * ceil_div(C, 32);
+  TDN_LAUNCH(nchw16_to_nhwc_kernel, dim3((int)(ntiles < 8192 ? ntiles : 8192)), dim3(256), 0, (hipStream_t)stream,
+             (const unsigned short*)src, s_n, s_c, s_h, s_w, N, C, H, W, (unsigned short*)dst);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
 template <bool F16>
 __global__ void nhwc_to_nchw_kernel(const bf16_t* src, int N, int C, int H, int W, float* dst) {
   __shared__ float t[32][33];

@@ -525,7 +525,15 @@ def to_nhwc_bf16(x, dtype=BF16):
         xp = x.permute(0, 2, 3, 1)
         if xp.is_contiguous():
             return xp
-        return xp.contiguous()
+        # a 16-bit tensor in another memory format (plain NCHW-contiguous cotangents, slices): the library's own
+        # transpose, not a PyTorch copy — every launch of the path then is one a recorded launch plan contains
+        _chk_dev(x, "x")
+        N, C, H, W = x.shape
+        out = torch.empty(N, H, W, C, dtype=dtype, device=x.device)
+        s = x.stride()
+        _lib.check(_lib.load().tdn_nchw16_to_nhwc(_ptr(x), s[0], s[1], s[2], s[3], N, C, H, W, _ptr(out),
+                                                  _lib.stream_ptr()), "tdn_nchw16_to_nhwc")
+        return out
     if x.dtype != torch.float32:
         x = x.float()
     N, C, H, W = x.shape
