@@ -475,7 +475,7 @@ def test_prepared_step_matches_eager(T):
     ps = T.PreparedStep(step, params=params, modules=(m, neck))
     assert ps.prepared, ps.error
     nl, ne, nw = ps.stats()
-    assert nl > 60 and ne > 0 and nw >= ne
+    assert nl > 60 and ne > 0 and nw > 0
     ps()
     ps()
     torch.cuda.synchronize()

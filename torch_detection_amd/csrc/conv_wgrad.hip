@@ -931,7 +931,7 @@ static int plan_group(const tdn_wgrad_item* items, int n, std::vector<ItemPlan>&
   const int shape_env = env_int("TDN_WGRAD_SHAPE", -1);   // force kTapShapes[id] where it divides the member
   const int s256 = env_int("TDN_WGRAD_S256", 5), s128 = env_int("TDN_WGRAD_S128", 4), s64 = env_int("TDN_WGRAD_S64", 2);
   const int uniform = env_int("TDN_WGRAD_UNIFORM", 0);   // 1: one tile shape per group (fewest launches)
-  const int tmin_tap = env_int("TDN_WGRAD_TMIN", 24), tmin_t9 = env_int("TDN_WGRAD9_TMIN", 40);
+  const int tmin_tap = env_int("TDN_WGRAD_TMIN", 24), tmin_t9 = env_int("TDN_WGRAD9_TMIN", 16);
   const int direct_ok = env_int("TDN_WGRAD_DIRECT", 1);
   int min_bmw = 256;
   for (int i = 0; i < n; ++i) {
