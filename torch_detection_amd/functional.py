@@ -1027,6 +1027,8 @@ class SeqNetFunction(torch.autograd.Function):
         need_net_dx = ctx.needs_input_grad[1] and net.stem is None
         g = None
         wq = WgradQueue(ctx.dev)
+        flush_every = int(os.environ.get('TDN_WGRAD_FLUSH', '0'))
+        since_flush = 0
         for bi in reversed(range(len(net.blocks))):
             b, sv = net.blocks[bi], saved[bi]
             if g is None:
@@ -1039,8 +1041,16 @@ class SeqNetFunction(torch.autograd.Function):
             need_dx = bi > 0 or net.stem is not None or need_net_dx
             g, gr = _block_bwd(b, sv, g, extra, mask_src, need_dx, wq)
             unit_grads.update(gr)
-            if b.ud is not None:
-                wq.flush()    # first block of a stage (resnet.py:130-136): the stage's weight gradients as one group
+            since_flush += 1
+            # Weight gradients are launched as groups: at the first block of a stage (resnet.py:130-136; the last one
+            # the backward pass reaches) and, inside long stages, every TDN_WGRAD_FLUSH blocks.  One group per stage
+            # is the most efficient launch, but it only becomes available when the stage's dgrad chain has ended: the
+            # timeline then alternates between stretches where a chain of small dgrad kernels has the GPU to itself
+            # (layer3: ~300 us) and bursts of weight-gradient work, and ends in a tail of weight gradients with nothing
+            # left beside them.  Half-stage groups keep both kinds of work on the GPU throughout.
+            if b.ud is not None or (flush_every > 0 and since_flush >= flush_every):
+                wq.flush()
+                since_flush = 0
         dx_in = None
         if net.stem is not None:
             if g is not None:
