@@ -13,7 +13,7 @@ import sys
 ROOT = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_bench"
 WANT = ("conv_gemm_kernel<192, 256, 64, 2, 4, 2, 6, 1", "conv_gemm_kernel<128, 128, 64, 2, 4, 2, 6, 0",
         "conv_gemm_kernel<192, 256, 64, 2, 4, 2, 6, 0", "conv_gemm_kernel<64, 64, 64, 2, 2, 2, 0, 0, 1",
-        "conv_wgrad9_kernel", "conv_wgrad_kernel<256, 64", "wgrad_finalize_kernel")
+        "conv_wgrad9_group_kernel", "conv_wgrad_group_kernel<256, 64", "wgrad_finalize_group_kernel")
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob(os.path.join(ROOT, "*", ""))):

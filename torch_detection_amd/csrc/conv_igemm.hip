@@ -739,6 +739,11 @@ static const GemmCfg kCfgs[] = {
     {192, 256, 64, 2, 4, 2, 11, 0},  // 55 staggered DMA issue (vs 3): K-step 2700 -> 2430 cycles traced, no gain in-step
     {192, 256, 64, 2, 4, 2, 11, 2},  // 56 traced
     {128, 128, 64, 2, 4, 2, 11, 0},  // 57 (vs 46)
+    {256, 64, 64, 4, 2, 2, 6, 0},    // 58 tall tiles for Cout = 64 layers: the 8 KB weight tile shared by 256 pixels
+    {192, 64, 64, 2, 2, 2, 6, 0},    // 59
+    {128, 64, 64, 2, 2, 2, 6, 0},    // 60
+    {256, 64, 64, 4, 2, 3, 6, 0},    // 61
+    {128, 64, 64, 2, 2, 3, 6, 0},    // 62
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -899,6 +904,11 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
     case 55: return launch_gemm<192, 256, 64, 2, 4, 2, 11, 0>(p, maxM, stream);
     case 56: return launch_gemm<192, 256, 64, 2, 4, 2, 11, 2>(p, maxM, stream);
     case 57: return launch_gemm<128, 128, 64, 2, 4, 2, 11, 0>(p, maxM, stream);
+    case 58: return launch_gemm<256, 64, 64, 4, 2, 2, 6, 0>(p, maxM, stream);
+    case 59: return launch_gemm<192, 64, 64, 2, 2, 2, 6, 0>(p, maxM, stream);
+    case 60: return launch_gemm<128, 64, 64, 2, 2, 2, 6, 0>(p, maxM, stream);
+    case 61: return launch_gemm<256, 64, 64, 4, 2, 3, 6, 0>(p, maxM, stream);
+    case 62: return launch_gemm<128, 64, 64, 2, 2, 3, 6, 0>(p, maxM, stream);
     default: TDN_CHECK(false, "bad GEMM config id"); return -1;
   }
 }
