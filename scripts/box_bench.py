@@ -78,6 +78,10 @@ def main():
         B.anchor_grid(base, fs, st)
     cpu = time.perf_counter() - t0
     report("anchor_grid 5 levels, %d anchors (5 launches)" % nanch, t, 17 * nanch, cpu, "launch-bound: 5 tiny launches")
+    gens = [ag] * 5
+    t = timeit(lambda: T.anchor_pyramid(gens, [fs for fs, _ in levels], [st for _, st in levels], dev), 20)
+    report("anchor_pyramid 5 levels, %d anchors (1 launch, incl. the operator layer's allocations)" % nanch, t,
+           17 * nanch, cpu)
     # ---- element-wise passes at bench size ----
     x = torch.randn(2, 400, 672, 64, device=dev).bfloat16()
     t = timeit(lambda: ops.maxpool3x3s2_fwd(x))
