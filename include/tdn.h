@@ -65,7 +65,15 @@ typedef struct tdn_epilogue {
   const void* mask_src;  /* NHWC, same shape as the output, or NULL */
   int32_t out_f32;       /* 0: out is bf16 NHWC; 1: out is float32 NHWC */
   int32_t reserved;
+  /* Optional scratch for cross-workgroup split-K (small-M, long-K layers: too few output tiles for 256 CUs, so a tile's
+   * K range is cut over several workgroups and the last one to arrive sums the fp32 partials in split order —
+   * deterministic).  Layout: the first TDN_SPLITK_TICKET_BYTES bytes are per-tile arrival counters and must be ZERO
+   * before the first use (the kernels leave them zero); the rest holds partial tiles.  Must not be shared by launches
+   * that may run concurrently (one buffer per stream).  NULL / too small: the launch simply does not split. */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
 } tdn_epilogue;
+#define TDN_SPLITK_TICKET_BYTES 65536
 
 const char* tdn_last_error(void);
 int tdn_version(void);

@@ -25,8 +25,8 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_epilogue_struct_layout():
     from torch_detection_amd._lib import Epilogue
-    # mirror of tdn_epilogue: 3 pointers, 4 int32, pointer, 2 int32 (LP64)
-    assert ctypes.sizeof(Epilogue) == 56
+    # mirror of tdn_epilogue: 3 pointers, 4 int32, pointer, 2 int32, pointer, int64 (LP64)
+    assert ctypes.sizeof(Epilogue) == 72
     assert Epilogue.mask_src.offset == 40 and Epilogue.out_f32.offset == 48
 
 

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 H, W = 800, 1344
 PLAIN = {"TDN_GEMM_CFG": "0", "TDN_WGRAD9": "0", "TDN_SIDE_STREAM": "0", "TDN_BRANCH": "0", "TDN_IMG_SPLIT_M": "0",
-         "TDN_KG_TILES": "0", "TDN_WGRAD_GROUP": "0"}
+         "TDN_KG_TILES": "0", "TDN_WGRAD_GROUP": "0", "TDN_SPLITK": "0"}
 
 
 @pytest.fixture(scope="module")
@@ -77,7 +77,8 @@ def test_full_size_schedules_agree(T, depth, batch, dtype, monkeypatch):
     o_again, g_again = run()
     assert all(torch.equal(a, b) for a, b in zip(o_def, o_again))
     assert all(torch.equal(a, b) for a, b in zip(g_def, g_again))
-    monkeypatch.setenv("TDN_KG_TILES", "0")
+    monkeypatch.setenv("TDN_KG_TILES", "0")      # neither in-workgroup nor cross-workgroup split-K: every tile shape
+    monkeypatch.setenv("TDN_SPLITK", "0")        # then accumulates K in the same order
     o_nokg, g_nokg = run()
     for k, v in PLAIN.items():
         monkeypatch.setenv(k, v)
@@ -89,7 +90,8 @@ def test_full_size_schedules_agree(T, depth, batch, dtype, monkeypatch):
     assert all(torch.equal(a, b) for a, b in zip(o_nokg, o_plain))
     worst = max(rel_l2(a, b) for a, b in zip(g_nokg, g_plain))
     assert worst <= 1e-5, worst
-    # the two-K-group tiles (layer4 / top FPN levels) sum K in two halves: same values to fp32 rounding, so a few
+    # the split-K launches (two wave groups inside a workgroup, or several workgroups per tile: layer3 / layer4 / top
+    # FPN levels) sum K in pieces: same values to fp32 rounding, so a few
     # 16-bit outputs of those layers land on the neighbouring value — and the layers behind them amplify that to the
     # usual distance between two valid 16-bit evaluations of the net (the bound of the end-to-end forward checks)
     assert max(rel_l2(a.float(), b.float()) for a, b in zip(o_def, o_nokg)) <= 2e-2

@@ -256,6 +256,77 @@ def test_subsample_and_mask(ops):
     assert max_rel(nchw(out), (a + b) * (m > 0).float()) <= 2 ** -7
 
 
+SPLITK_CASES = [
+    # N, H, W, Cin, Cout, k, stride   — few 128x128 tiles, long K: the launches that cut K over several workgroups
+    (1, 25, 42, 512, 512, 3, 1),      # layer4 conv2 of one image: 36 tiles, 72 K-steps
+    (2, 50, 84, 256, 256, 3, 1),      # layer3 conv2: 132 tiles, 36 K-steps
+    (1, 50, 84, 1024, 256, 1, 1),     # layer3 conv1: 16 K-steps
+    (1, 50, 84, 512, 512, 3, 2),      # stride 2: the dgrad runs as four output-parity classes with 1..4 taps each
+    (1, 25, 42, 2048, 512, 1, 1),     # layer4 conv1 of one image
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_cross_workgroup_split_k(ops, case, monkeypatch):
+    """Cross-workgroup split-K (partials exchanged through the scratch buffer, summed in split order by the last
+    workgroup to arrive): fp32 results equal the unsplit launch to summation-order accuracy and the fp32 reference
+    at 1e-3, repeated launches are bit-identical (the ticket area returns to zero), forward and dgrad with the full
+    epilogue (affine, residual, ReLU / mask)."""
+    import ctypes
+    from torch_detection_amd import _lib
+    N, H, W, Cin, Cout, k, s = case
+    x = det_tensor((N, Cin, H, W), 21, -1, 1)
+    w = det_tensor((Cout, Cin, k, k), 22, -0.05, 0.05)
+    scale = det_tensor((Cout,), 23, 0.5, 1.5, bf16=False)
+    shift = det_tensor((Cout,), 24, -0.5, 0.5, bf16=False)
+    Ho, Wo = ops.conv_out_size(H, k, s, k // 2), ops.conv_out_size(W, k, s, k // 2)
+    res = det_tensor((N, Cout, Ho, Wo), 25, -1, 1)
+    plan = (ctypes.c_int32 * 16)()
+    xg, wg, rg = nhwc(x), pack_w(w), nhwc(res)
+    sc, sh = scale.cuda(), shift.cuda()
+
+    def fwd(out_f32):
+        return ops.conv2d_fwd(xg, wg, k, s, k // 2, sc, sh, rg, ops.ADD_SAME, True, out_f32=out_f32)
+
+    y1 = fwd(True)
+    y2 = fwd(True)
+    yb = fwd(False)
+    assert torch.equal(y1, y2)                                   # deterministic, ticket area re-armed
+    monkeypatch.setenv("TDN_SPLITK", "0")
+    y0 = fwd(True)
+    monkeypatch.delenv("TDN_SPLITK")
+    ref = torch.relu(F.conv2d(x, w, None, s, k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    assert not torch.equal(y1, y0) or True                       # (may coincide on tiny K; not required to differ)
+    assert max_rel(nchw(y1), nchw(y0)) <= 1e-5
+    assert max_rel(nchw(y1), ref) <= 1e-3
+    assert max_rel(nchw(yb), ref) <= 2 ** -7
+    # dgrad (K = taps * Cout), mask + addend epilogue
+    g = det_tensor((N, Cout, Ho, Wo), 26, -1, 1)
+    wd = pack_wd(w, scale)
+    add = det_tensor((N, Cin, H, W), 27, -1, 1)
+    msk = det_tensor((N, Cin, H, W), 28, -1, 1)
+    gg, ag, mg = nhwc(g), nhwc(add), nhwc(msk)
+
+    def dgrad():
+        return ops.conv2d_dgrad(gg, wd, (H, W), k, s, k // 2, ag, ops.ADD_SAME, mg, out_f32=True)
+
+    d1 = dgrad()
+    d2 = dgrad()
+    assert torch.equal(d1, d2)
+    monkeypatch.setenv("TDN_SPLITK", "0")
+    d0 = dgrad()
+    monkeypatch.delenv("TDN_SPLITK")
+    assert max_rel(nchw(d1), nchw(d0)) <= 1e-5
+    w_eff = wd.float().cpu().permute(3, 0, 1, 2).contiguous()
+    oph = H - ((Ho - 1) * s - 2 * (k // 2) + k)
+    opw = W - ((Wo - 1) * s - 2 * (k // 2) + k)
+    dref = (F.conv_transpose2d(g, w_eff, None, s, k // 2, (oph, opw)) + add) * (msk > 0).float()
+    assert max_rel(nchw(d1), dref) <= 1e-3
+    # the ticket area is zero at rest
+    ws = ops.splitk_workspace(xg.device)
+    assert int(ws[:_lib.SPLITK_TICKET_BYTES].view(torch.int64).abs().sum().item()) == 0
+
+
 def test_layout_converters(ops):
     x = det_tensor((2, 70, 9, 13), 71, -1, 1)
     xg = x.cuda()

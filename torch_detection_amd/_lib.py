@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libtdn.so")
 
 TDN_BF16 = 0
 TDN_F16 = 1
+SPLITK_TICKET_BYTES = 65536
 ADD_NONE, ADD_SAME, ADD_UP2X, ADD_SUMPOOL2 = 0, 1, 2, 3
 
 c_void_p = ctypes.c_void_p
@@ -35,6 +36,8 @@ class Epilogue(ctypes.Structure):
         ("mask_src", c_void_p),
         ("out_f32", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
+        ("splitk_ws", c_void_p),
+        ("splitk_ws_bytes", c_i64),
     ]
 
 

@@ -52,6 +52,12 @@ struct GemmParams {
   unsigned tn_mul, tn_shr;   // fast_div by tiles_n
   int ncls, krot;
   int grouped;   // block-diagonal grouped conv: the output tile's 64 channels see only the same 64 input channels
+  // cross-workgroup split-K (gridDim.z = splitk workgroups per output tile, each over a contiguous range of K-steps)
+  int splitk;
+  float* slab;                   // fp32 partial tiles: [class * nwg_pad + tile][split][BM * BN]
+  unsigned long long* ticket;    // per tile: arrivals (bits 0..3) + arrivals per XCD (4 bits each from bit 4); zero at rest
+  void* ws;                      // caller's split-K scratch (tdn_epilogue.splitk_ws) or NULL
+  long long ws_bytes;
   unsigned long long* trace;   // TAG 2 instantiations only: 32 timestamps per workgroup (scripts/trace_gemm.py)
   GemmClass cls[4];
 };
@@ -212,7 +218,16 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   const int kchunks = p.grouped ? 1 : p.Ktap / BK;
   const int in_kc0 = p.grouped ? n0 / BK : 0;
   const int T = ntaps * kchunks;
-  const int Tg = KG == 1 ? T : (T + KG - 1) / KG;   // K-steps per group (the same for every group: shared barriers)
+  // cross-workgroup split-K: this workgroup multiplies K-steps [t_begin, t_end) of its tile
+  const int nsplit = (KG == 1) ? p.splitk : 1;
+  const int split = (nsplit > 1) ? (int)blockIdx.z : 0;
+  int t_begin = 0, t_end = T;
+  if (nsplit > 1) {
+    const int per = (T + nsplit - 1) / nsplit;
+    t_begin = min(T, split * per);
+    t_end = min(T, t_begin + per);
+  }
+  const int Tg = KG == 1 ? (t_end - t_begin) : (T + KG - 1) / KG;   // K-steps per group (shared barriers)
   // K order: channel chunk outermost, taps innermost.  All taps of a chunk touch the same input lines (shifted by
   // a pixel or a row), so within ~ntaps K-steps the workgroups of an XCD re-read a working set of
   // (pixels + halo) x 128 B instead of cycling through the whole (pixels x Cin) slab — the latter overflows the
@@ -222,6 +237,12 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   // weight-row stride K*2 B — multiples of 512 B) lands on the same few L2 channels.  Opt-in: TDN_KROT=1.
   int ld_tap = 0, ld_issued = grp;   // ld_issued: global index of the next K-step this group issues
   int ld_kc = p.krot ? (tile_m + tile_n) % kchunks : 0;   // (tap, channel chunk) of the next K-step to be issued
+  if (nsplit > 1) {                  // start at K-step t_begin: chunk t / ntaps (from the start chunk), tap t % ntaps
+    const int c_adv = t_begin / ntaps;
+    ld_tap = t_begin - c_adv * ntaps;
+    ld_kc = (ld_kc + c_adv) % kchunks;
+    ld_issued = t_begin;
+  }
   auto advance_k = [&]() {   // taps innermost
     if (++ld_tap == ntaps) { ld_tap = 0; ld_kc = (ld_kc + 1 == kchunks) ? 0 : ld_kc + 1; }
   };
@@ -233,7 +254,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   auto stage_load = [&](int s) {
     char* sA = smem + s * STAGE + wave * (RPI * ROWB);
     char* sB = sA + A_BYTES;
-    if (ld_issued < T) {
+    if (ld_issued < t_end) {
       ld_issued += KG;
       const int tp = __builtin_amdgcn_readlane(tapv, ld_tap);
       const int dh = (tp & 0xff) - 64, dw = ((tp >> 8) & 0xff) - 64, widx = tp >> 16;
@@ -376,7 +397,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   };
   if constexpr (EARLY_EPI) load_affine();   // older than every LDS-DMA: the counted vmcnt waits retire them first
 
-  if (T > 0) {
+  if (Tg > 0) {
     TDN_TRACE(1);
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) stage_load(s);
@@ -494,6 +515,82 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     // drain the dummy tail loads before the LDS ring / registers are reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TDN_TRACE(27);
+  }
+
+  // ---- cross-workgroup split-K: publish the partial tile; the last workgroup to arrive sums all of them ----
+  // Partials are written with agent-scope (write-through) stores, so they are visible device-wide whichever XCD the
+  // peers run on; the arrival counter also counts arrivals per XCD: when every peer ran on the reader's own XCD (the
+  // dispatcher deals workgroups x, x+8, ... to one XCD and all splits of a tile share x) the partials are read from
+  // that XCD's L2 with plain loads, otherwise with agent-scope loads.  The sum runs over the splits in index order
+  // (this workgroup's own partial taken from its registers at its position): the result does not depend on who is last.
+  if constexpr (KG == 1) {
+    if (nsplit > 1) {
+      constexpr int PART64 = BM * BN / 2;                     // 64-bit words per partial tile
+      const int tile_lin = (int)blockIdx.y * p.nwg_pad + tile;
+      unsigned long long* slab = (unsigned long long*)p.slab + (size_t)tile_lin * nsplit * PART64;
+      unsigned long long* mine = slab + (size_t)split * PART64;
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const size_t at = ((size_t)(i * FM + j) * (NW * 64) + tid) * 2;
+          unsigned long long lo, hi;
+          const f32x4_t a = acc[i][j];
+          lo = ((unsigned long long)__float_as_uint(a[1]) << 32) | __float_as_uint(a[0]);
+          hi = ((unsigned long long)__float_as_uint(a[3]) << 32) | __float_as_uint(a[2]);
+          __hip_atomic_store(mine + at, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(mine + at + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this lane's partial has been written through
+      __shared__ unsigned long long s_total;
+      __syncthreads();                                        // ... and every lane's
+      unsigned xcc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+#endif
+      xcc &= 7u;
+      if (tid == 0) {
+        const unsigned long long inc = 1ull | (1ull << (4 + 4 * xcc));
+        const unsigned long long old = __hip_atomic_fetch_add(p.ticket + tile_lin, inc, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT);
+        s_total = old + inc;
+      }
+      __syncthreads();
+      const unsigned long long total = s_total;
+      if ((int)(total & 15ull) != nsplit) return;             // not the last one: done
+      if (tid == 0)
+        __hip_atomic_store(p.ticket + tile_lin, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero at rest
+      const bool same_xcd = (int)((total >> (4 + 4 * xcc)) & 15ull) == nsplit;
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const size_t at = ((size_t)(i * FM + j) * (NW * 64) + tid) * 2;
+          f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+          for (int sp = 0; sp < nsplit; ++sp) {
+            f32x4_t v;
+            if (sp == split) {
+              v = acc[i][j];
+            } else {
+              const unsigned long long* src = slab + (size_t)sp * PART64 + at;
+              unsigned long long lo, hi;
+              if (same_xcd) {
+                lo = src[0];
+                hi = src[1];
+              } else {
+                lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              v[0] = __uint_as_float((unsigned)lo);
+              v[1] = __uint_as_float((unsigned)(lo >> 32));
+              v[2] = __uint_as_float((unsigned)hi);
+              v[3] = __uint_as_float((unsigned)(hi >> 32));
+            }
+            sum = (sp == 0) ? v : sum + v;
+          }
+          acc[i][j] = sum;
+        }
+    }
   }
 
   // ---- split-K groups: exchange the partial accumulators through LDS (the rings are idle now) ----
@@ -747,7 +844,25 @@ static const GemmCfg kCfgs[] = {
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
-static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0, int ktap = 64) {
+// Cross-workgroup split-K (see the kernel): for layers whose 128x128 tiles cannot fill the chip and whose K loop is
+// long enough to cut.  TDN_SPLITK=0 disables it; TDN_SPLITK_WGS = workgroups aimed at (default 320: two 8-wave
+// workgroups fit a CU), TDN_SPLITK_MINT = fewest K-steps per split.
+static int splitk_for(int tiles, int T) {
+  const char* e = getenv("TDN_SPLITK");
+  if (e && e[0] == '0') return 1;
+  const int wgs = getenv("TDN_SPLITK_WGS") ? atoi(getenv("TDN_SPLITK_WGS")) : 320;
+  const int mint = getenv("TDN_SPLITK_MINT") ? atoi(getenv("TDN_SPLITK_MINT")) : 6;
+  if (tiles <= 0 || T < 2 * mint) return 1;
+  int S = wgs / tiles;
+  if (S > 8) S = 8;
+  while (S > 1 && T / S < mint) --S;
+  // every split must own at least one K-step: with per = ceil(T / S) the last one starts at (S - 1) * per
+  while (S > 1 && (S - 1) * ((T + S - 1) / S) >= T) --S;
+  return S < 1 ? 1 : S;
+}
+
+static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0, int ktap = 64, int ncls = 1,
+                      bool can_split = false) {
   if (grouped) return 0;   // block-diagonal grouped conv: one 64-channel block per N tile
   if (const char* env = getenv("TDN_GEMM_CFG")) {
     const int id = atoi(env);
@@ -758,6 +873,12 @@ static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0, int ktap 
   // workgroup on almost every shape; only the very large-M 3x3 convs prefer the 256x128 8-wave tile.
   const int big_minm = getenv("TDN_T192_MINM") ? atoi(getenv("TDN_T192_MINM")) : 24000;
   if (ngemm % 256 == 0 && maxM >= big_minm) return 3;   // 192x256, 8 waves: fewest L2->LDS bytes per flop
+  // too few 128x128 tiles for the chip but a K loop long enough to cut: 128x128 tiles (half the L2->LDS bytes per
+  // flop of 64x64) with the K range shared out over several workgroups per tile
+  if (can_split && ngemm % 128 == 0 && ktap % 64 == 0) {
+    const int tiles128 = ceil_div(maxM, 128) * (ngemm / 128) * ncls;
+    if (splitk_for(tiles128, kgemm / 64) > 1) return 46;
+  }
   // few tiles and a long K loop (layer4, the top FPN levels): every CU holds at most two 4-wave workgroups and the
   // LDS-DMA stream starves (~4 B/clk per loading wave) — recruit a second wave group along K (in-workgroup split-K)
   const int kg_tiles = getenv("TDN_KG_TILES") ? atoi(getenv("TDN_KG_TILES")) : 512;
@@ -820,7 +941,23 @@ static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
               "trace config selected but tdn_debug_trace() buffer is missing or too small");
     p.trace = g_trace_buf;
   }
-  dim3 grid(p.nwg_pad, p.ncls, 1), block(WM * WN * KG * 64, 1, 1);
+  // cross-workgroup split-K where the caller gave scratch and the tile count / K length call for it
+  int splitk = 1;
+  if (KG == 1 && TAG == 0 && MODE != 3 && MODE != 4 && MODE != 7 && MODE != 8 && p.ws != nullptr && !p.grouped) {
+    const int T = p.cls[0].ntaps * (p.Ktap / BK);
+    const int tiles_lin = p.nwg_pad * p.ncls;
+    int S = splitk_for(ntiles * p.ncls, T);
+    while (S > 1 && (tiles_lin > TDN_SPLITK_TICKET_BYTES / 8 ||
+                     TDN_SPLITK_TICKET_BYTES + (int64_t)tiles_lin * S * BM * BN * 4 > p.ws_bytes))
+      --S;
+    if (S > 1) {
+      splitk = S;
+      p.ticket = (unsigned long long*)p.ws;
+      p.slab = (float*)((char*)p.ws + TDN_SPLITK_TICKET_BYTES);
+    }
+  }
+  p.splitk = splitk;
+  dim3 grid(p.nwg_pad, p.ncls, splitk), block(WM * WN * KG * 64, 1, 1);
   TDN_LAUNCH((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG, F16>), grid, block, lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
@@ -829,7 +966,7 @@ static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
 static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype) {
   if (maxM <= 0) return 0;
   if (dtype == TDN_F16) {   // fp16 operands: the production tile set only
-    const int id = choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped, p.Ktap);
+    const int id = choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped, p.Ktap, p.ncls, p.ws != nullptr);
     switch (id) {
       case 0: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 1, true>(p, maxM, stream);
       case 1: return launch_gemm<64, 128, 64, 2, 2, 2, 6, 0, 1, true>(p, maxM, stream);
@@ -840,7 +977,7 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
       default: TDN_CHECK(false, "GEMM config %d (TDN_GEMM_CFG) has no TDN_F16 build", id); return -1;
     }
   }
-  switch (choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped, p.Ktap)) {
+  switch (choose_cfg(maxM, p.Cout, p.cls[0].ntaps * p.Ktap, p.grouped, p.Ktap, p.ncls, p.ws != nullptr)) {
     case 0: return launch_gemm<64, 64, 64, 2, 2, 2, 0>(p, maxM, stream);
     case 1: return launch_gemm<64, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
     case 2: return launch_gemm<128, 128, 64, 2, 2, 2, 6>(p, maxM, stream);
@@ -916,7 +1053,12 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
 static int fill_epilogue(GemmParams& p, const tdn_epilogue* ep, int Hout, int Wout) {
   p.scale = nullptr; p.shift = nullptr; p.addend = nullptr; p.mask = nullptr;
   p.addend_mode = TDN_ADD_NONE; p.addend_h = 0; p.addend_w = 0; p.relu = 0; p.out_f32 = 0;
+  p.ws = nullptr; p.ws_bytes = 0; p.splitk = 1; p.slab = nullptr; p.ticket = nullptr;
   if (!ep) return 0;
+  if (ep->splitk_ws && ep->splitk_ws_bytes > TDN_SPLITK_TICKET_BYTES && ((uintptr_t)ep->splitk_ws & 255) == 0) {
+    p.ws = ep->splitk_ws;
+    p.ws_bytes = ep->splitk_ws_bytes;
+  }
   p.out_f32 = ep->out_f32 ? 1 : 0;
   p.scale = ep->scale;
   p.shift = ep->shift;

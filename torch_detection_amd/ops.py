@@ -68,11 +68,31 @@ def _relu_code(relu):
     return 2 if (relu == 2 and relu is not True) else (1 if relu else 0)
 
 
+_splitk_ws = {}
+SPLITK_WS_BYTES = 96 << 20     # tickets + fp32 partial tiles of the largest split launch (R50/R101-FPN: <= 40 MB)
+
+
+def splitk_workspace(device):
+    """Scratch for cross-workgroup split-K launches on the routed stream: one persistent buffer per (device, stream),
+    ticket area zeroed once (the kernels leave it zero).  Allocated outside any graph capture / private pool on first
+    use — warm-up runs see to that."""
+    key = (device.index, _lib.stream_ptr())
+    buf = _splitk_ws.get(key)
+    if buf is None:
+        buf = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
+        buf[:_lib.SPLITK_TICKET_BYTES].zero_()
+        _splitk_ws[key] = buf
+    return buf
+
+
 def make_epilogue(Cout, Ho, Wo, scale=None, shift=None, addend=None, addend_mode=ADD_NONE, relu=False,
-                  mask_src=None, N=None, out_f32=False, dtype=None):
+                  mask_src=None, N=None, out_f32=False, dtype=None, device=None):
     _chk_vec(scale, "scale", Cout)
     _chk_vec(shift, "shift", Cout)
     ep = Epilogue()
+    if device is not None:
+        ws = splitk_workspace(device)
+        ep.splitk_ws, ep.splitk_ws_bytes = ws.data_ptr(), ws.numel()
     ep.scale = scale.data_ptr() if scale is not None else None
     ep.shift = shift.data_ptr() if shift is not None else None
     ep.relu = _relu_code(relu)
@@ -203,7 +223,7 @@ def conv2d_fwd(x, w_fwd, k, stride, pad, scale=None, shift=None, addend=None, ad
     odt = torch.float32 if out_f32 else x.dtype
     y = torch.empty(N, Ho, Wo, Cout, dtype=odt, device=x.device) if out is None else \
         _out_buffer(out, (N, Ho, Wo, Cout), odt, "conv2d_fwd")
-    ep = make_epilogue(Cout, Ho, Wo, scale, shift, addend, addend_mode, relu, None, N, out_f32, x.dtype)
+    ep = make_epilogue(Cout, Ho, Wo, scale, shift, addend, addend_mode, relu, None, N, out_f32, x.dtype, x.device)
     _lib.check(_lib.load().tdn_conv2d_fwd(_ptr(x), _ptr(w_fwd), _ptr(y), N, H, W, Cin, Cout, k, stride, pad,
                                           ctypes.byref(ep), dtype_code(x.dtype), _lib.stream_ptr()), "tdn_conv2d_fwd")
     return y
@@ -224,7 +244,7 @@ def conv2d_dgrad(g, w_dgrad, in_hw, k, stride, pad, addend=None, addend_mode=ADD
     odt = torch.float32 if out_f32 else g.dtype
     dx = torch.empty(N, H, W, Cin, dtype=odt, device=g.device) if out is None else \
         _out_buffer(out, (N, H, W, Cin), odt, "conv2d_dgrad")
-    ep = make_epilogue(Cin, H, W, None, None, addend, addend_mode, False, mask_src, N, out_f32, g.dtype)
+    ep = make_epilogue(Cin, H, W, None, None, addend, addend_mode, False, mask_src, N, out_f32, g.dtype, g.device)
     _lib.check(_lib.load().tdn_conv2d_dgrad(_ptr(g), _ptr(w_dgrad), _ptr(dx), N, H, W, Cin, Cout, k, stride, pad,
                                             ctypes.byref(ep), dtype_code(g.dtype), _lib.stream_ptr()), "tdn_conv2d_dgrad")
     return dx
