@@ -845,11 +845,15 @@ static const GemmCfg kCfgs[] = {
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
 // Cross-workgroup split-K (see the kernel): for layers whose 128x128 tiles cannot fill the chip and whose K loop is
-// long enough to cut.  TDN_SPLITK=0 disables it; TDN_SPLITK_WGS = workgroups aimed at (default 320: two 8-wave
-// workgroups fit a CU), TDN_SPLITK_MINT = fewest K-steps per split.
+// long enough to cut.  OFF unless TDN_SPLITK=1: measured on MI355X (scripts/conv_bench.py, every layer3 / layer4 /
+// top-FPN shape at batch 1 and 2) the exchange costs more than the shorter K loops gain — 11 -> 21 us for the
+// 2048->256 lateral, 28 -> 37 us for layer4's 3x3, 437-443 -> 403 img/s for the step: partials and the arrival
+// counter must be coherent across XCDs (agent scope: write-through stores, memory-side atomic, L2-bypassing loads),
+// and that store-ack -> atomic -> load chain is ~10 us of serial latency per tile whatever the volume.
+// TDN_SPLITK_WGS = workgroups aimed at (default 320), TDN_SPLITK_MINT = fewest K-steps per split.
 static int splitk_for(int tiles, int T) {
   const char* e = getenv("TDN_SPLITK");
-  if (e && e[0] == '0') return 1;
+  if (!(e && e[0] == '1')) return 1;
   const int wgs = getenv("TDN_SPLITK_WGS") ? atoi(getenv("TDN_SPLITK_WGS")) : 320;
   const int mint = getenv("TDN_SPLITK_MINT") ? atoi(getenv("TDN_SPLITK_MINT")) : 6;
   if (tiles <= 0 || T < 2 * mint) return 1;
