@@ -206,11 +206,14 @@ def main():
     RefPAFPN = NECKS.module_dict["PAFPN"]
     man["pafpn_keys"] = manifest_of(RefPAFPN(chans, 64, 5))
     pf = {}
-    for tag, actv in (("none", None), ("relu", "relu")):
+    for tag, actv in (("none", None), ("relu", "relu"), ("relu6", "relu6")):
         pa = RefPAFPN(chans, 64, 5, activation=actv)
         sdp = fill_state_dict(pa.state_dict(), 800)
         pa.load_state_dict(sdp)
-        pins = [det_tensor((2, c, h, w), 810 + i, -1.0, 1.0).requires_grad_(True) for i, (c, (h, w)) in
+        # relu6: inputs x4 so that a visible share of the PA activations saturates at 6 (where nn.ReLU6 passes no
+        # gradient — the case a plain-ReLU backward mask would get wrong)
+        amp = 4.0 if actv == "relu6" else 1.0
+        pins = [det_tensor((2, c, h, w), 810 + i, -amp, amp).requires_grad_(True) for i, (c, (h, w)) in
                 enumerate(zip(chans, sizes))]
         pouts = pa(pins)
         pcots = [det_tensor(tuple(o.shape), 820 + i, -1.0, 1.0) for i, o in enumerate(pouts)]
@@ -232,6 +235,10 @@ def main():
         for k, p in pa.named_parameters():
             if k.startswith("pa_convs") or tag == "none":
                 pf["%s/grad/%s" % (tag, k)] = p.grad.numpy()
+        if actv == "relu6":
+            sat = [float((o.detach() >= 6).float().mean()) for o in pouts[1:4]]
+            assert max(sat) > 0.01, "relu6 golden case does not saturate anywhere: %s" % sat
+            man["pafpn_relu6_saturated_fraction"] = sat
     # RetinaNet-style extra levels: stride-2 convs on the last backbone input (pafpn.py:139-147), 6 outputs
     pa = RefPAFPN(chans, 64, 6, add_extra_convs=True)
     sdp = fill_state_dict(pa.state_dict(), 830)

@@ -199,18 +199,23 @@ def test_weight_update_is_picked_up(T):
     assert not torch.equal(y0, y1)
 
 
-@pytest.mark.parametrize("tag,actv", [("none", None), ("relu", "relu")])
+@pytest.mark.parametrize("tag,actv", [("none", None), ("relu", "relu"), ("relu6", "relu6")])
 def test_pafpn_vs_golden(T, manifest, golden_dir, tag, actv):
-    """PAFPN on the HIP path vs vectors captured from the reference import."""
+    """PAFPN on the HIP path vs vectors captured from the reference import.  The relu6 case feeds
+    inputs four times as large, so that a visible share of the PA activations sits at the clamp (fractions in the
+    manifest): the backward mask 0 < y < 6 of nn.ReLU6 (layers.py:117-118) is exercised, not just y > 0."""
     meta = manifest["pafpn_small"]
     gold = np.load(os.path.join(golden_dir, "pafpn.npz"))
     mod = T.PAFPN(meta["in_channels"], meta["out_channels"], meta["num_outs"], activation=actv)
     mod.load_state_dict(fill_state_dict(mod.state_dict(), meta["state_seed"]))
     mod.cuda()
-    ins = [det_tensor((meta["N"], c, h, w), meta["in_seed0"] + i, -1, 1).cuda().requires_grad_(True)
+    amp = 4.0 if actv == "relu6" else 1.0
+    ins = [det_tensor((meta["N"], c, h, w), meta["in_seed0"] + i, -amp, amp).cuda().requires_grad_(True)
            for i, (c, (h, w)) in enumerate(zip(meta["in_channels"], meta["sizes"]))]
     outs = mod(ins)
     assert len(outs) == meta["num_outs"]
+    if actv == "relu6":
+        assert max(float((o >= 6).float().mean()) for o in outs[1:4]) > 0.01
     cots = [det_tensor(tuple(o.shape), meta["cot_seed0"] + i, -1, 1).cuda().to(o.dtype) for i, o in enumerate(outs)]
     torch.autograd.backward(outs, cots)
     eo = [rel_l2(_f32(o), torch.from_numpy(gold["%s/out%d" % (tag, i)])) for i, o in enumerate(outs)]

@@ -139,7 +139,7 @@ def test_constructor_and_registry_semantics(manifest):
     assert "gn1.weight" in g.state_dict()
 
 
-@pytest.mark.parametrize("tag,actv", [("none", None), ("relu", "relu")])
+@pytest.mark.parametrize("tag,actv", [("none", None), ("relu", "relu"), ("relu6", "relu6")])
 def test_pafpn_oracle_bit_exact(manifest, golden_dir, tag, actv):
     """PAFPN (models/necks/pafpn.py:103-148)."""
     import torch_detection_amd as T
@@ -151,7 +151,8 @@ def test_pafpn_oracle_bit_exact(manifest, golden_dir, tag, actv):
     assert _keys(mod) == manifest["pafpn_keys"]
     sd = fill_state_dict(mod.state_dict(), meta["state_seed"])
     ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ins = [det_tensor((meta["N"], c, h, w), meta["in_seed0"] + i, -1, 1).requires_grad_(True)
+    amp = 4.0 if actv == "relu6" else 1.0      # the relu6 case saturates (oracle/gen_golden.py)
+    ins = [det_tensor((meta["N"], c, h, w), meta["in_seed0"] + i, -amp, amp).requires_grad_(True)
            for i, (c, (h, w)) in enumerate(zip(meta["in_channels"], meta["sizes"]))]
     outs = O.pafpn_forward(ps, ins, meta["num_outs"], actv)
     cots = [det_tensor(tuple(o.shape), meta["cot_seed0"] + i, -1, 1) for i, o in enumerate(outs)]
