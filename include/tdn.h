@@ -74,6 +74,10 @@ typedef struct tdn_epilogue {
   int64_t splitk_ws_bytes;
 } tdn_epilogue;
 #define TDN_SPLITK_TICKET_BYTES 65536
+/* One-time device probe (allocates and frees a few KB, synchronises the device — call it outside any stream capture;
+ * torch_detection_amd._lib.load() does): do workgroups with equal blockIdx.x always run on the same XCD?  1 yes, 0 no.
+ * The XCD-local form of the split-K exchange (TDN_SPLITK=1) is only used when it returned 1. */
+int tdn_probe_xcd_mapping(void);
 
 const char* tdn_last_error(void);
 int tdn_version(void);

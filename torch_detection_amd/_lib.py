@@ -155,6 +155,7 @@ SIGNATURES = {
     "tdn_plan_run": (c_int, [c_void_p]),
     "tdn_plan_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "tdn_plan_free": (c_int, [c_void_p]),
+    "tdn_probe_xcd_mapping": (c_int, []),
     "tdn_conv2d_plan": (c_int, [c_int] * 9 + [ctypes.POINTER(ctypes.c_int32)]),
     "tdn_debug_trace": (c_int, [c_void_p, ctypes.c_longlong]),
 }
@@ -178,6 +179,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    if torch.cuda.is_available() and os.environ.get("TDN_SPLITK", "0") == "1":
+        lib.tdn_probe_xcd_mapping()    # once per process, before anything could be capturing a stream
     return lib
 
 

@@ -13,6 +13,7 @@
 // A "class" is a sub-lattice of output pixels sharing one tap list: forward and stride-1 dgrad have one
 // class; stride-2 dgrad has four output-parity classes (gather form, no atomics, no zero-insertion).
 #include "common.h"
+#include <vector>
 
 struct GemmClass {
   int Ha, Wa, M;     // rows m -> (img, a, b) over an Ha x Wa lattice; M = N*Ha*Wa
@@ -54,6 +55,7 @@ struct GemmParams {
   int grouped;   // block-diagonal grouped conv: the output tile's 64 channels see only the same 64 input channels
   // cross-workgroup split-K (gridDim.z = splitk workgroups per output tile, each over a contiguous range of K-steps)
   int splitk;
+  int split_local;               // XCD-local exchange (the dispatch-to-XCD mapping was verified), else agent scope
   float* slab;                   // fp32 partial tiles: [class * nwg_pad + tile][split][BM * BN]
   unsigned long long* ticket;    // per tile: arrivals (bits 0..3) + arrivals per XCD (4 bits each from bit 4); zero at rest
   void* ws;                      // caller's split-K scratch (tdn_epilogue.splitk_ws) or NULL
@@ -518,30 +520,38 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
   }
 
   // ---- cross-workgroup split-K: publish the partial tile; the last workgroup to arrive sums all of them ----
-  // Partials are written with agent-scope (write-through) stores, so they are visible device-wide whichever XCD the
-  // peers run on; the arrival counter also counts arrivals per XCD: when every peer ran on the reader's own XCD (the
-  // dispatcher deals workgroups x, x+8, ... to one XCD and all splits of a tile share x) the partials are read from
-  // that XCD's L2 with plain loads, otherwise with agent-scope loads.  The sum runs over the splits in index order
-  // (this workgroup's own partial taken from its registers at its position): the result does not depend on who is last.
+  // The sum runs over the splits in index order (this workgroup's own partial taken from its registers at its
+  // position): the result does not depend on who is last.  Two ways to exchange:
+  //   * XCD-local (p.split_local): all splits of a tile share blockIdx.x, and a dispatch hands workgroup x to XCD
+  //     x mod 8 (each XCD takes its share of the packet; checked once per process by tdn_probe_xcd_mapping) — so the
+  //     peers share ONE L2, which is the coherence point of its CUs: plain stores, an L2 atomic, an L1 invalidate and
+  //     plain loads, ~1 us.  The arrival counter also counts arrivals per XCD; a peer on another XCD would never
+  //     complete the count — the probe is what rules that out.
+  //   * agent scope: write-through stores, a memory-side atomic and L2-bypassing loads — correct wherever the peers
+  //     run, but ~10 us of serial latency per tile (measured slower than not splitting on every layer).
   if constexpr (KG == 1) {
     if (nsplit > 1) {
       constexpr int PART64 = BM * BN / 2;                     // 64-bit words per partial tile
       const int tile_lin = (int)blockIdx.y * p.nwg_pad + tile;
       unsigned long long* slab = (unsigned long long*)p.slab + (size_t)tile_lin * nsplit * PART64;
       unsigned long long* mine = slab + (size_t)split * PART64;
+      const bool local = p.split_local != 0;
 #pragma unroll
       for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
           const size_t at = ((size_t)(i * FM + j) * (NW * 64) + tid) * 2;
-          unsigned long long lo, hi;
           const f32x4_t a = acc[i][j];
-          lo = ((unsigned long long)__float_as_uint(a[1]) << 32) | __float_as_uint(a[0]);
-          hi = ((unsigned long long)__float_as_uint(a[3]) << 32) | __float_as_uint(a[2]);
-          __hip_atomic_store(mine + at, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(mine + at + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (local) {
+            *(f32x4_t*)(mine + at) = a;
+          } else {
+            const unsigned long long lo = ((unsigned long long)__float_as_uint(a[1]) << 32) | __float_as_uint(a[0]);
+            const unsigned long long hi = ((unsigned long long)__float_as_uint(a[3]) << 32) | __float_as_uint(a[2]);
+            __hip_atomic_store(mine + at, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + at + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this lane's partial has been written through
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this lane's partial has reached L2 / memory
       __shared__ unsigned long long s_total;
       __syncthreads();                                        // ... and every lane's
       unsigned xcc = 0;
@@ -551,16 +561,22 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
       xcc &= 7u;
       if (tid == 0) {
         const unsigned long long inc = 1ull | (1ull << (4 + 4 * xcc));
-        const unsigned long long old = __hip_atomic_fetch_add(p.ticket + tile_lin, inc, __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long old;
+        if (local) old = __hip_atomic_fetch_add(p.ticket + tile_lin, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else old = __hip_atomic_fetch_add(p.ticket + tile_lin, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_total = old + inc;
       }
       __syncthreads();
       const unsigned long long total = s_total;
       if ((int)(total & 15ull) != nsplit) return;             // not the last one: done
-      if (tid == 0)
-        __hip_atomic_store(p.ticket + tile_lin, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero at rest
+      if (tid == 0) {                                         // zero at rest
+        if (local) __hip_atomic_store(p.ticket + tile_lin, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(p.ticket + tile_lin, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       const bool same_xcd = (int)((total >> (4 + 4 * xcc)) & 15ull) == nsplit;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (local) asm volatile("buffer_inv sc0" ::: "memory");   // nothing of the slab may come from this CU's L1
+#endif
 #pragma unroll
       for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -573,18 +589,16 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
               v = acc[i][j];
             } else {
               const unsigned long long* src = slab + (size_t)sp * PART64 + at;
-              unsigned long long lo, hi;
-              if (same_xcd) {
-                lo = src[0];
-                hi = src[1];
+              if (local || same_xcd) {
+                v = *(const f32x4_t*)src;
               } else {
-                lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[0] = __uint_as_float((unsigned)lo);
+                v[1] = __uint_as_float((unsigned)(lo >> 32));
+                v[2] = __uint_as_float((unsigned)hi);
+                v[3] = __uint_as_float((unsigned)(hi >> 32));
               }
-              v[0] = __uint_as_float((unsigned)lo);
-              v[1] = __uint_as_float((unsigned)(lo >> 32));
-              v[2] = __uint_as_float((unsigned)hi);
-              v[3] = __uint_as_float((unsigned)(hi >> 32));
             }
             sum = (sp == 0) ? v : sum + v;
           }
@@ -844,16 +858,67 @@ static const GemmCfg kCfgs[] = {
 };
 static const int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
+// ---- workgroup -> XCD mapping probe -------------------------------------------------------------------------------
+// The XCD-local split-K exchange needs every workgroup with the same blockIdx.x to run on the same XCD whatever its
+// blockIdx.y / z.  That is how a dispatch is shared out (every XCD takes the workgroups whose linear id is congruent
+// to its index; grid.x is a multiple of 8 here); this probe checks it on the device once per process — three grid
+// shapes, HW_REG_XCC_ID per workgroup — and the XCD-local mode is only used if it held.
+__global__ void xcd_probe_kernel(unsigned* out) {
+  if (threadIdx.x == 0) {
+    unsigned xcc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+#endif
+    out[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = xcc & 15u;
+  }
+}
+
+static int g_xcd_static = -1;   // -1 not probed, 0 mapping does not hold (or probe failed), 1 holds
+
+extern "C" int tdn_probe_xcd_mapping(void) {
+  if (g_xcd_static >= 0) return g_xcd_static;
+  const int shapes[3][3] = {{64, 1, 4}, {40, 4, 3}, {264, 1, 7}};
+  unsigned* dev = nullptr;
+  const size_t cap = 264 * 7 * 4;
+  if (hipMalloc(&dev, cap * sizeof(unsigned)) != hipSuccess) { g_xcd_static = 0; return 0; }
+  std::vector<unsigned> host(cap);
+  int ok = 1;
+  for (int s = 0; s < 3 && ok; ++s) {
+    const int gx = shapes[s][0], gy = shapes[s][1], gz = shapes[s][2];
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3(gx, gy, gz), dim3(512), 0, nullptr, dev);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(host.data(), dev, (size_t)gx * gy * gz * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) {
+      ok = 0;
+      break;
+    }
+    for (int z = 0; z < gz && ok; ++z)
+      for (int y = 0; y < gy && ok; ++y)
+        for (int x = 0; x < gx; ++x)
+          if (host[((size_t)z * gy + y) * gx + x] != host[x % 8]) { ok = 0; break; }
+  }
+  (void)hipFree(dev);
+  g_xcd_static = ok;
+  return ok;
+}
+
 // Cross-workgroup split-K (see the kernel): for layers whose 128x128 tiles cannot fill the chip and whose K loop is
-// long enough to cut.  OFF unless TDN_SPLITK=1: measured on MI355X (scripts/conv_bench.py, every layer3 / layer4 /
-// top-FPN shape at batch 1 and 2) the exchange costs more than the shorter K loops gain — 11 -> 21 us for the
-// 2048->256 lateral, 28 -> 37 us for layer4's 3x3, 437-443 -> 403 img/s for the step: partials and the arrival
-// counter must be coherent across XCDs (agent scope: write-through stores, memory-side atomic, L2-bypassing loads),
-// and that store-ack -> atomic -> load chain is ~10 us of serial latency per tile whatever the volume.
+// long enough to cut.  OFF by default: measured on MI355X (scripts/conv_bench.py, every layer3 / layer4 / top-FPN
+// shape at batch 1 and 2) it loses to the tuned unsplit tiles in both exchange modes — one image, unsplit / XCD-local
+// / agent scope: layer4 3x3 28 / 32 / 37 us, 2048->512 11 / 21 / 24, 2048->256 lateral 11 / 16 / 21, layer3 3x3
+// 19 / 22 / 29; whole step 436 / 420 / 403 img/s.  The agent-scope chain (write-through stores, memory-side atomic,
+// L2-bypassing loads) is ~10 us of serial latency per tile; the XCD-local one ~4 us — still more than the shorter
+// K loops save, because what bounds these launches is the per-workgroup fixed cost, which splitting multiplies.
 // TDN_SPLITK_WGS = workgroups aimed at (default 320), TDN_SPLITK_MINT = fewest K-steps per split.
-static int splitk_for(int tiles, int T) {
+// TDN_SPLITK: 0 off, 1 XCD-local exchange (needs the probe to have passed, else off), 2 agent-scope exchange.
+static int splitk_mode() {
   const char* e = getenv("TDN_SPLITK");
-  if (!(e && e[0] == '1')) return 1;
+  const int m = (e && *e) ? atoi(e) : 0;
+  if (m == 1) return g_xcd_static == 1 ? 1 : 0;
+  return m == 2 ? 2 : 0;
+}
+
+static int splitk_for(int tiles, int T) {
+  if (splitk_mode() == 0) return 1;
   const int wgs = getenv("TDN_SPLITK_WGS") ? atoi(getenv("TDN_SPLITK_WGS")) : 320;
   const int mint = getenv("TDN_SPLITK_MINT") ? atoi(getenv("TDN_SPLITK_MINT")) : 6;
   if (tiles <= 0 || T < 2 * mint) return 1;
@@ -961,6 +1026,7 @@ static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
     }
   }
   p.splitk = splitk;
+  p.split_local = splitk_mode() == 1 ? 1 : 0;
   dim3 grid(p.nwg_pad, p.ncls, splitk), block(WM * WN * KG * 64, 1, 1);
   TDN_LAUNCH((conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG, F16>), grid, block, lds, stream, p);
   TDN_LAUNCH_CHECK();
