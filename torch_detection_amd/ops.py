@@ -6,6 +6,7 @@ shapes on the host before launching (a mis-shaped launch can fault the GPU), enq
 current HIP stream, and never synchronises.  There is no non-HIP fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -90,7 +91,9 @@ def make_epilogue(Cout, Ho, Wo, scale=None, shift=None, addend=None, addend_mode
     _chk_vec(scale, "scale", Cout)
     _chk_vec(shift, "shift", Cout)
     ep = Epilogue()
-    if device is not None:
+    if device is not None and os.environ.get("TDN_SPLITK", "0") not in ("", "0"):
+        # cross-workgroup split-K is off by default (csrc/conv_igemm.hip: splitk_for): no scratch is handed over,
+        # and none is allocated, unless it has been switched on
         ws = splitk_workspace(device)
         ep.splitk_ws, ep.splitk_ws_bytes = ws.data_ptr(), ws.numel()
     ep.scale = scale.data_ptr() if scale is not None else None
