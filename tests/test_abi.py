@@ -80,3 +80,19 @@ def test_host_side_plans_and_errors():
     assert lib.tdn_conv2d_plan(0, 2, 25, 42, 500, 512, 3, 2, 1, o) != 0
     assert b"multiples of 64" in lib.tdn_last_error()
     assert lib.tdn_conv2d_plan(0, 1, 8, 8, 64, 64, 5, 1, 2, o) != 0
+
+
+def test_launch_plan_bookkeeping_without_a_gpu():
+    """tdn_plan_*: recording state machine and error reporting (no launches, no events: nothing touches a device)."""
+    from torch_detection_amd import _lib
+    lib = _lib.load()
+    assert lib.tdn_plan_event_record(None) == -1            # nothing is being recorded
+    assert lib.tdn_plan_begin() == 0
+    assert lib.tdn_plan_begin() != 0 and b"already" in lib.tdn_last_error()
+    plan = lib.tdn_plan_end()
+    assert plan
+    out = (ctypes.c_int32 * 3)()
+    assert lib.tdn_plan_stats(plan, out) == 0 and list(out) == [0, 0, 0]
+    assert lib.tdn_plan_free(plan) == 0
+    assert not lib.tdn_plan_end() and b"no plan" in lib.tdn_last_error()
+    assert lib.tdn_plan_run(None) != 0
