@@ -391,14 +391,16 @@ def _gn_dz(u, g):
     return dz
 
 
-def unit_dgrad(u, g, in_hw, addend=None, addend_mode=ADD_NONE, mask_src=None):
+def unit_dgrad(u, g, in_hw, addend=None, addend_mode=ADD_NONE, mask_src=None, out=None):
     if addend is None:
         addend_mode = ADD_NONE
+    if out is not None and (u.gn or u.bnt or u.groups > 1):
+        raise NotImplementedError('caller-provided outputs: plain conv (+ folded BN) units only')
     if u.gn or u.bnt:
         g = _gn_dz(u, g)
     if u.groups > 1:
         return ops.gconv2d_dgrad(g, u.w_dgrad, u.groups, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
-    dx = ops.conv2d_dgrad(g, u.w_dgrad, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src)
+    dx = ops.conv2d_dgrad(g, u.w_dgrad, in_hw, u.k, u.stride, u.pad, addend, addend_mode, mask_src, out=out)
     if DEBUG_BWD is not None:
         DEBUG_BWD.append(('dgrad', u, g, tuple(in_hw), addend, addend_mode, mask_src, dx))
     return dx
@@ -940,6 +942,52 @@ def _block_bwd(b, saved, g, extra, mask_src, need_dx, wq=None):
     return dx, grads
 
 
+def _block_bwd_chains(b, saved, g, extra, mask_src, wq, pool, cuts):
+    """_block_bwd with the dgrad launches of every image range issued on that range's stream (see
+    SeqNetFunction._backward): outputs are slices of batch tensors allocated here, weight gradients are queued on the
+    batch tensors as usual.  Needs need_dx, and `extra` only where the block has a downsample conv."""
+    x, h1, h2, out = saved
+    grads = {}
+    dev = g.device
+
+    def new_like(t):
+        return torch.empty_like(t)
+
+    bott = b.kind == 'bottleneck'
+    g2 = new_like(h2) if bott else None
+    g1 = new_like(h1)
+    dx = new_like(x)
+    t = new_like(x) if b.ud is not None else g
+    for i, st in enumerate(pool[:len(cuts) - 1]):
+        a, e = cuts[i], cuts[i + 1]
+        prev = _lib.set_stream_override(st.cuda_stream)
+        try:
+            gi = g[a:e]
+            if b.ud is not None:
+                unit_dgrad(b.ud, gi, _hw(x), extra[a:e] if extra is not None else None, ADD_SAME, out=t[a:e])
+            if bott:
+                unit_dgrad(b.u3, gi, _hw(h2), mask_src=h2[a:e], out=g2[a:e])
+                unit_dgrad(b.u2, g2[a:e], _hw(h1), mask_src=h1[a:e], out=g1[a:e])
+            else:
+                unit_dgrad(b.u2, gi, _hw(h1), mask_src=h1[a:e], out=g1[a:e])
+            unit_dgrad(b.u1, g1[a:e], _hw(x), t[a:e], ADD_SAME, mask_src[a:e] if mask_src is not None else None,
+                       out=dx[a:e])
+        finally:
+            _lib.set_stream_override(prev)
+    if bott:
+        grads[b.u3] = unit_wgrad(b.u3, h2, g, queue=wq)
+        grads[b.u2] = unit_wgrad(b.u2, h1, g2, queue=wq)
+    else:
+        grads[b.u2] = unit_wgrad(b.u2, h1, g, queue=wq)
+    grads[b.u1] = unit_wgrad(b.u1, x, g1, queue=wq)
+    if b.ud is not None:
+        grads[b.ud] = unit_wgrad(b.ud, x, g, queue=wq)
+    # nothing of this block may be recycled before the chains have run: t is only referenced here
+    key = (dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
+    _side_refs.setdefault(key, []).extend(v for v in (t, g, g1, g2, dx) if v is not None)
+    return dx, grads
+
+
 def _stem_fwd(u, xp, hw):
     """conv7x7/s2 + norm + ReLU of the stem (resnet.py:254-257): BN folded into the conv epilogue, or GroupNorm."""
     if not (u.gn or u.bnt):
@@ -1029,6 +1077,31 @@ class SeqNetFunction(torch.autograd.Function):
         wq = WgradQueue(ctx.dev)
         flush_every = int(os.environ.get('TDN_WGRAD_FLUSH', '0'))
         since_flush = 0
+        # Per-image dgrad chains (default; TDN_BWD_SPLIT=0 turns them off): like the forward's, the dgrad launches of
+        # each image range go to that range's stream, block by block in alternation — the stretches of the backward
+        # pass where a chain of small dgrad kernels had the GPU to itself become two half-size chains side by side
+        # (443 -> 459 img/s).  The weight-gradient groups still see batch tensors, so the main stream joins the chains
+        # before every group is launched.
+        chains = None
+        nimg = saved[0][0].shape[0] if saved else 0
+        if os.environ.get('TDN_BWD_SPLIT', '1') != '0' and nimg >= 2 and (net.stem is not None or need_net_dx) and \
+                all(_splittable(b_) for b_ in net.blocks) and \
+                all(net.blocks[k + 1].ud is not None for k in ext if k + 1 < len(net.blocks)):
+            dev = ctx.dev
+            key = (dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
+            ways = max(2, min(nimg, int(os.environ.get('TDN_IMG_SPLIT_WAYS', '4'))))
+            pool = _split_streams.get(key)
+            if pool is None or len(pool) < ways:
+                pool = [torch.cuda.Stream(device=dev) for _ in range(ways)]
+                _split_streams[key] = pool
+            chains = (pool[:ways], [nimg * i // ways for i in range(ways + 1)])
+        main = torch.cuda.current_stream(ctx.dev)
+
+        def join_chains():
+            for st_ in chains[0]:
+                streams.wait_stream(main, st_)
+
+        started = False
         for bi in reversed(range(len(net.blocks))):
             b, sv = net.blocks[bi], saved[bi]
             if g is None:
@@ -1039,7 +1112,17 @@ class SeqNetFunction(torch.autograd.Function):
             extra = ext.get(bi - 1) if bi > 0 else None
             mask_src = saved[bi - 1][3] if bi > 0 else None
             need_dx = bi > 0 or net.stem is not None or need_net_dx
-            g, gr = _block_bwd(b, sv, g, extra, mask_src, need_dx, wq)
+            if chains is not None and need_dx:
+                if not started:        # the chains start behind everything the main stream has produced so far
+                    ev0 = streams.record(main)
+                    for st_ in chains[0]:
+                        streams.wait(st_, ev0)
+                    started = True
+                g, gr = _block_bwd_chains(b, sv, g, extra, mask_src, wq, chains[0], chains[1])
+            else:
+                if chains is not None and started:
+                    join_chains()      # this block runs on the main stream and reads what the chains produced
+                g, gr = _block_bwd(b, sv, g, extra, mask_src, need_dx, wq)
             unit_grads.update(gr)
             since_flush += 1
             # Weight gradients are launched as groups: at the first block of a stage (resnet.py:130-136; the last one
@@ -1049,8 +1132,12 @@ class SeqNetFunction(torch.autograd.Function):
             # (layer3: ~300 us) and bursts of weight-gradient work, and ends in a tail of weight gradients with nothing
             # left beside them.  Half-stage groups keep both kinds of work on the GPU throughout.
             if b.ud is not None or (flush_every > 0 and since_flush >= flush_every):
+                if chains is not None and started:
+                    join_chains()
                 wq.flush()
                 since_flush = 0
+        if chains is not None and started:
+            join_chains()
         dx_in = None
         if net.stem is not None:
             if g is not None:
