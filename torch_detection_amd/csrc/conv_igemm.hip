@@ -15,6 +15,14 @@
 #include "common.h"
 #include <vector>
 
+// conv_halo.hip: LDS-resident activation patch kernel for 3x3 / 1x1 convs (stride-1 3x3, any 1x1 forward; stride-1
+// input gradients).  Each returns 1 when it launched, 0 when the shape stays with the generic kernel below.
+int tdn_halo_conv_fwd(const void* x, const void* w_fwd, void* y, int N, int H, int W, int Cin, int Cout, int k,
+                      int stride, int pad, const tdn_epilogue* ep, int dtype, hipStream_t stream);
+int tdn_halo_conv_dgrad(const void* g, const void* w_dgrad, void* dx, int N, int H, int W, int Cin, int Cout, int k,
+                        int stride, int pad, const tdn_epilogue* ep, int dtype, hipStream_t stream);
+int tdn_halo_plan(int kind, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad, int32_t* o);
+
 struct GemmClass {
   int Ha, Wa, M;     // rows m -> (img, a, b) over an Ha x Wa lattice; M = N*Ha*Wa
   int oh0, ow0;      // output pixel = (a*so + oh0, b*so + ow0)
@@ -1223,6 +1231,10 @@ extern "C" int tdn_conv2d_fwd(const void* x, const void* w_fwd, void* y, int N, 
   build_fwd(p, N, H, W, Cin, Cout, k, stride, pad);
   p.in = (const bf16_t*)x; p.wt = (const bf16_t*)w_fwd; p.out = (bf16_t*)y;
   if (fill_epilogue(p, ep, p.Hout, p.Wout)) return -1;
+  if (!getenv("TDN_GEMM_CFG")) {   // a forced generic tile (tests, sweeps) keeps the generic kernel
+    const int h = tdn_halo_conv_fwd(x, w_fwd, y, N, H, W, Cin, Cout, k, stride, pad, ep, dtype, (hipStream_t)stream);
+    if (h != 0) return h < 0 ? h : 0;
+  }
   return dispatch_gemm(p, p.cls[0].M, (hipStream_t)stream, dtype);
 }
 
@@ -1235,6 +1247,11 @@ extern "C" int tdn_conv2d_dgrad(const void* g, const void* w_dgrad, void* dx, in
   const int maxM = build_dgrad(p, N, H, W, Cin, Cout, k, stride, pad);
   p.in = (const bf16_t*)g; p.wt = (const bf16_t*)w_dgrad; p.out = (bf16_t*)dx;
   if (fill_epilogue(p, ep, p.Hout, p.Wout)) return -1;
+  if (!getenv("TDN_GEMM_CFG")) {
+    const int h = tdn_halo_conv_dgrad(g, w_dgrad, dx, N, H, W, Cin, Cout, k, stride, pad, ep, dtype,
+                                      (hipStream_t)stream);
+    if (h != 0) return h < 0 ? h : 0;
+  }
   return dispatch_gemm(p, maxM, (hipStream_t)stream, dtype);
 }
 
@@ -1316,5 +1333,6 @@ extern "C" int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout,
   o[0] = Mtot; o[1] = p.Cout; o[2] = p.cls[0].ntaps * p.Ktap; o[3] = t.bm; o[4] = t.bn; o[5] = t.bk;
   o[6] = (ceil_div(maxM, t.bm) * (p.Cout / t.bn) + 7) & ~7; o[7] = p.ncls; o[8] = 1; o[9] = p.ncls;
   o[10] = p.cls[0].ntaps; o[11] = 1; o[12] = taps_tot; o[13] = p.Hout; o[14] = p.Wout; o[15] = maxM;
+  if (!getenv("TDN_GEMM_CFG")) (void)tdn_halo_plan(kind, N, H, W, Cin, Cout, k, stride, pad, o);   // o[8] >= 100: halo kernel
   return 0;
 }
