@@ -87,7 +87,7 @@ __device__ __forceinline__ void halo_wait_vm_and_barrier() {
 // it is placed in the wave's stream), so a wave that both loads and multiplies serialises the two.  Loader waves
 // (one per SIMD, next to one consumer wave) take the issue stalls; consumers only read LDS and feed the matrix pipe.
 template <int FM, int FN, int WM, int WN, int NST, int NTAPS, int XI9, bool F16, int ABL = 0, int NWL = 0>
-__global__ __launch_bounds__((WM * WN + NWL) * 64, ((WM * WN + NWL) >= 16 ? 4 : 2)) void conv_halo_kernel(const HaloParams p) {
+__global__ __launch_bounds__((WM * WN + NWL) * 64, ((WM * WN + NWL) >= 16 ? 4 : ((WM * WN + NWL) > 8 ? 3 : 2))) void conv_halo_kernel(const HaloParams p) {
   extern __shared__ __attribute__((aligned(1024))) char halo_smem[];
   constexpr int NW = WM * WN;            // consumer waves
   constexpr int NWLD = NWL > 0 ? NWL : NW;   // waves that issue LDS-DMA
@@ -575,6 +575,7 @@ static const HaloCfg kHalo3[] = {
     {2, 4, 2, 2, 7, 1, 4},   // 9   64 x 128, 4 consumer + 4 loader waves
     {4, 2, 2, 2, 5, 1, 4},   // 10 128 x  64, 4 consumer + 4 loader waves
     {4, 4, 2, 2, 4, 1, 4},   // 11 configuration 8 with a 4-deep ring
+    {4, 4, 4, 2, 4, 2, 4},   // 12 256 x 128, 8 consumer + 4 loader waves (3 waves per SIMD: <= 168 registers)
 };
 static const HaloCfg kHalo1[] = {
     {4, 4, 2, 2, 5, 1},   // 0  128 x 128, 4 waves
@@ -650,9 +651,9 @@ static bool halo_make_plan(const HaloShape& s, HaloPlan* pl) {
   // many small co-resident workgroups hide better (measured 1.3-2x slower here).
   int cfg = -1;
   if (s.k == 3 && s.Cout % 128 == 0) {
-    if (M >= 100000) cfg = 1;
-    else if (M >= 3000 && M < 30000) cfg = 11;
-    else if (M < 3000 && s.Cin >= 512) cfg = 10;
+    if (M >= 100000) cfg = 1;                       // fpn_convs.0 and its dgrad
+    else if (M >= 6000 && M < 30000) cfg = 11;      // layer2 per image, layer3 / P4 per batch: 128 x 128, 4 + 4 waves
+    else if (M < 6000 && s.Cin >= 256) cfg = 10;    // layer3 / layer4 per image: 128 x 64, 4 + 4 waves
   }
   cfg = halo_env_int(s.k == 3 ? "TDN_HALO_CFG3" : "TDN_HALO_CFG1", cfg);
   if (cfg < 0 || cfg >= (s.k == 3 ? kNumHalo3 : kNumHalo1)) return false;   // (-1: not taken)
@@ -727,6 +728,7 @@ static int halo_dispatch3(int cfg, const HaloParams& p, size_t lds, hipStream_t 
     case 9: return halo_launch<2, 4, 2, 2, 7, 9, 1, F16, 0, 4>(p, lds, stream);
     case 10: return halo_launch<4, 2, 2, 2, 5, 9, 1, F16, 0, 4>(p, lds, stream);
     case 11: return halo_launch<4, 4, 2, 2, 4, 9, 1, F16, 0, 4>(p, lds, stream);
+    case 12: return halo_launch<4, 4, 4, 2, 4, 9, 2, F16, 0, 4>(p, lds, stream);
     default: TDN_CHECK(false, "bad 3x3 halo config %d", cfg); return -1;
   }
 }
