@@ -398,7 +398,9 @@ int tdn_collate_images(const void* const* imgs, const int32_t* hw, const uint8_t
 
 /* Describes the GEMM decomposition the library would launch for a conv: fills out[0..15] with
  * {M, Ngemm, Kgemm, BM, BN, BK, grid_x, grid_y, grid_z, nclasses, ntaps(class0), splitk, ...}.
- * kind: 0 = fwd, 1 = dgrad, 2 = wgrad. */
+ * kind: 0 = fwd, 1 = dgrad, 2 = wgrad.  A shape taken by the LDS-resident patch kernel (csrc/conv_halo.hip: 3x3
+ * stride-1 convs) reports grid_z = 100 + its configuration id, out[11] = patch rows * 1000 + patch columns and
+ * out[12] = chunk images held in LDS * 100 + output-channel passes per workgroup. */
 int tdn_conv2d_plan(int kind, int N, int H, int W, int Cin, int Cout, int k, int stride, int pad,
                     int32_t* out16);
 

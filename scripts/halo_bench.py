@@ -93,7 +93,7 @@ def main():
             tot["halo"] += us_g * cnt
             tot["best"] += us_g * cnt
             continue
-        variants = [("dflt[c%d %dx%d xb%d]" % (o[8] - 100, o[9], o[11], o[12]), {})]
+        variants = [("dflt[c%d %dx%d xb%d]" % (o[8] - 100, o[11] // 1000, o[11] % 1000, o[12] // 100), {})]
         cfgkey = "TDN_HALO_CFG3" if k == 3 else "TDN_HALO_CFG1"
         for c in [c for c in (args.cfg3 if k == 3 else args.cfg1).split(",") if c]:
             variants.append(("c" + c, {cfgkey: c}))

@@ -898,7 +898,8 @@ int tdn_halo_plan(int kind, int N, int H, int W, int Cin, int Cout, int k, int s
   halo_fill(p, s, pl);
   const HaloCfg& c = halo_cfg(k, pl.cfg);
   o[3] = c.fm * c.wm * 16; o[4] = c.fn * c.wn * 16; o[5] = 64; o[6] = p.nwg_pad; o[7] = 1;
-  o[8] = 100 + pl.cfg;   // 100 + halo configuration id (0 = generic GEMM tile)
-  o[9] = pl.TH; o[10] = k == 3 ? 9 : 1; o[11] = pl.TW; o[12] = pl.xbuf;
+  o[8] = 100 + pl.cfg;                      // grid_z slot: 100 + halo configuration id (generic kernel: split count)
+  o[11] = pl.TH * 1000 + pl.TW;             // split-K slot: the patch, TH * 1000 + TW (1x1: 1000 + BM)
+  o[12] = pl.xbuf * 100 + pl.nt_per_wg;     // chunk images in LDS * 100 + output-channel passes per workgroup
   return 1;
 }

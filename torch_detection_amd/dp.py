@@ -15,7 +15,8 @@ gradient sum.  This module supplies that exchange:
     bucket — RCCL then runs concurrently with the rest of backward;
   * xGMI is point-to-point (7 links x ~153 GB/s per GPU), so buckets are kept large (default 32 MiB: 4 buckets
     for R50-FPN's 107 MB) and RCCL is left to spread rings/channels over all links;
-  * ``finish()`` makes the compute stream wait for the comm stream and applies the 1/world average;
+  * ``finish()`` makes the compute stream wait for the comm stream; the 1/world average happens inside the
+    collective (RCCL ``ReduceOp.AVG``), or — gloo, 16-bit wire — in the one pass that touches the reduced buckets;
   * ``comm_dtype=torch.bfloat16`` halves the bytes on the links (53.7 MB instead of 107.4 MB for R50-FPN): each bucket
     is rounded to bfloat16 into a staging buffer on the comm stream, reduced in bfloat16, and written back to the
     fp32 buffer in ``finish()``.  The sum then carries bfloat16 rounding (8 significant bits) — an option for
@@ -65,6 +66,10 @@ class GradReducer(object):
                 cur_start, cur_slots = end, 0
         self.use_streams = self.device.type == 'cuda'
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_streams else None
+        # RCCL divides inside the collective (ReduceOp.AVG): no extra pass over the 107 MB buffer in finish(); gloo
+        # has no AVG, and integer-free 16-bit wire sums are averaged while they are widened back to fp32
+        self._avg_in_collective = bool(self.enabled and self.average and self.world > 1 and self.use_streams and
+                                       self.comm_dtype is None and dist.get_backend(group) == 'nccl')
         self._pending = None
         self._works = []
         self.reset()
@@ -73,21 +78,26 @@ class GradReducer(object):
         self._pending = [b[2] for b in self.buckets]
         self._works = []
         self._launched = []                            # buckets reduced this step, in launch order
-        self._produced = set()                         # slots written this step (when the producers report them)
+        self._produced = set()                         # slots written this step (the producers report them)
+        self._unreported = set()                       # buckets with a producer that did not say which slots it wrote
         self._producers = [{} for _ in self.buckets]   # raw stream -> stream that wrote into each bucket this step
 
     def mark_ready(self, slot, stream=None):
         """Slot's gradient has been enqueued on ``stream`` (default: the current stream); launch its bucket's
         all-reduce if complete."""
-        self.mark_ready_n(self.bucket_of[slot], 1, stream)
+        self.mark_ready_n(self.bucket_of[slot], 1, stream, slots=(slot,))
 
     def mark_ready_n(self, b, count, stream=None, slots=None):
         """``count`` slots of bucket ``b`` have been enqueued on ``stream`` (one call per conv unit from the backward
         schedule: a unit's weight / affine gradients are consecutive slots, normally of one bucket).  ``slots``: which
-        ones — lets ``finish()`` zero the slots nobody wrote this step before it reduces a partly filled bucket."""
+        ones — lets ``finish()`` zero the slots nobody wrote this step before it reduces a partly filled bucket.
+        Without ``slots`` the bucket is marked as having unreported producers: its stale slots cannot be told apart and
+        ``finish()`` refuses to reduce it partly filled."""
         self._pending[b] -= count
         if slots is not None:
             self._produced.update(slots)
+        else:
+            self._unreported.add(b)
         if self.use_streams and stream is not None:
             self._producers[b][stream.cuda_stream] = stream
         if self._pending[b] == 0:
@@ -114,7 +124,8 @@ class GradReducer(object):
             with torch.cuda.stream(self.comm_stream):
                 if wire is not buf:
                     wire.copy_(buf)            # fp32 -> 16-bit, round to nearest even, on the comm stream
-                w = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w = dist.all_reduce(wire, op=dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM,
+                                    group=self.group, async_op=True)
         else:
             if wire is not buf:
                 wire.copy_(buf)
@@ -126,23 +137,35 @@ class GradReducer(object):
         missing = [i for i, p in enumerate(self._pending) if p > 0]
         if missing:
             # gradients that were never produced this step (e.g. frozen stages): their slots still hold the last
-            # step's already averaged values — zero them (where the producers reported their slots), then reduce
-            if self._produced:
-                for s_, (o, n) in enumerate(zip(self.offsets, self.numels)):
-                    if self.bucket_of[s_] in missing and s_ not in self._produced:
-                        self.flat[o:o + n].zero_()
+            # step's already averaged values — zero every slot of a partly filled bucket that no producer reported,
+            # unconditionally, then reduce
+            bad = [b for b in missing if b in self._unreported]
+            if bad:
+                raise RuntimeError('GradReducer.finish(): buckets %s are partly filled and a producer did not report '
+                                   'its slots (mark_ready_n(..., slots=...)): stale gradients cannot be zeroed' % bad)
+            for s_, (o, n) in enumerate(zip(self.offsets, self.numels)):
+                if self.bucket_of[s_] in missing and s_ not in self._produced:
+                    self.flat[o:o + n].zero_()
             for b in missing:
                 self._launch(b)
         for w in self._works:
             w.wait()
         if self.use_streams and self.enabled:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        scale = 1.0 / self.world if (self.average and self.world > 1 and not self._avg_in_collective) else None
         if self.comm_buf is not None and self.enabled:
-            for b in self._launched:           # 16-bit sums back into the fp32 gradient views
+            # 16-bit sums back into the fp32 gradient views, the 1/world average folded into the same pass
+            for b in self._launched:
                 start, end, _ = self.buckets[b]
-                self.flat[start:end].copy_(self.comm_buf[start:end])
-        if self.average and self.world > 1:
-            self.flat.mul_(1.0 / self.world)
+                if scale is None:
+                    self.flat[start:end].copy_(self.comm_buf[start:end])
+                else:
+                    torch.mul(self.comm_buf[start:end], scale, out=self.flat[start:end])
+        elif scale is not None:
+            # only the reduced buckets carry a sum; one pass over them (no pass at all when the collective averaged)
+            for b in (self._launched if self.enabled else range(len(self.buckets))):
+                start, end, _ = self.buckets[b]
+                self.flat[start:end].mul_(scale)
         self.reset()
 
 

@@ -540,6 +540,10 @@ class WgradQueue(object):
         self.device = device
         self.members = []      # (unit, item, side-stream group tag)
         self.per_layer = os.environ.get('TDN_WGRAD_GROUP', '1') == '0'
+        # called at the start of every flush: the owner's way of making the CURRENT stream see every recorded g.
+        # The per-image dgrad chains write g on streams of their own; a flush that only orders the side stream
+        # behind the main stream would race with them (per-layer flushes happen in the middle of a block).
+        self.pre_flush = None
 
     def add(self, u, x_in, g, img_hw=None):
         """Gradients aligned with ``u.params()`` (written when the group is flushed).  With a gradient sink attached
@@ -614,6 +618,8 @@ class WgradQueue(object):
         """Enqueue everything recorded so far."""
         if not self.members:
             return
+        if self.pre_flush is not None:
+            self.pre_flush()
         members, self.members = self.members, []
         dev = self.device
         ev = None
@@ -1104,6 +1110,9 @@ class SeqNetFunction(torch.autograd.Function):
                 streams.wait_stream(main, st_)
 
         started = False
+        if chains is not None:
+            # a flush from inside a block (TDN_WGRAD_GROUP=0 flushes per layer) must see the chains' g tensors too
+            wq.pre_flush = lambda: join_chains() if started else None
         for bi in reversed(range(len(net.blocks))):
             b, sv = net.blocks[bi], saved[bi]
             if g is None:

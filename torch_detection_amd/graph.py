@@ -138,6 +138,12 @@ class PreparedStep(object):
     ~30 us of host time per launch in the operator layer (~6.7 ms per ResNet-50-FPN step, for ~4.4 ms of GPU work);
     the plan spends the ~3 us of the runtime's launch call.
 
+    Ordering and device: a replay enqueues on the RAW streams of the recorded run (the stream that was current while
+    recording, and the library's side / chain streams), not on the caller's current stream — work the caller enqueued
+    elsewhere must be ordered against it explicitly; ``tdn_plan_run`` selects the recording device for the duration
+    of the call.  Only launches made by the recording thread are part of the plan (others are counted by
+    ``tdn_plan_stats``'s return value).
+
     Same contract as ``GraphedStep``: ``fn`` must use the same tensors every time and must not synchronise; its
     results (``param.grad``, whatever it stores) are the tensors of the recorded run, overwritten by each replay —
     they live in a private memory pool owned by this object.  Only the library's own launches are replayed: a step
@@ -172,6 +178,8 @@ class PreparedStep(object):
                     fn()
             finally:
                 self.plan = self._lib.tdn_plan_end()
+                # replays never go through autograd: the setting is only needed while recording
+                torch.autograd.set_multithreading_enabled(mt)
             if not self.plan:
                 _lib.check(-1, "tdn_plan_end")
             torch.cuda.synchronize()
@@ -196,9 +204,7 @@ class PreparedStep(object):
                       % (type(e).__name__, e), file=sys.stderr)
             torch.cuda.synchronize()
         finally:
-            self._mt = mt
-            if self.plan is None:
-                torch.autograd.set_multithreading_enabled(mt)
+            torch.autograd.set_multithreading_enabled(mt)
 
     @property
     def prepared(self):
@@ -225,7 +231,6 @@ class PreparedStep(object):
             torch.cuda.synchronize()
             self._lib.tdn_plan_free(self.plan)
             self.plan = None
-            torch.autograd.set_multithreading_enabled(self._mt)
 
     def __del__(self):
         try:

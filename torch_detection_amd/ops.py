@@ -80,8 +80,14 @@ def splitk_workspace(device):
     key = (device.index, _lib.stream_ptr())
     buf = _splitk_ws.get(key)
     if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("split-K scratch for this stream does not exist yet: run the step once outside the "
+                               "capture (warm-up) so that it is allocated and zeroed there")
         buf = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
         buf[:_lib.SPLITK_TICKET_BYTES].zero_()
+        # the zeroing ran on torch's current stream, the launches that use the tickets go to the ROUTED stream (a
+        # chain / branch / side stream): order them once, here, instead of on every launch
+        torch.cuda.current_stream(device).synchronize()
         _splitk_ws[key] = buf
     return buf
 
