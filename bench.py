@@ -43,7 +43,7 @@ def dominant_traffic():
         blocks = re.split(r"\n\s*\n", txt)
         for b in blocks:      # the first kernel entry is the tagged dominant launch
             m = re.search(r"HBM bytes per launch: corrected ([0-9.eE+]+)", b)
-            if m and "conv_gemm_kernel" in b:
+            if m and ("conv_halo_kernel" in b or "conv_gemm_kernel" in b):
                 return float(m.group(1)), os.path.relpath(f, ROOT)
     return None, None
 
@@ -67,10 +67,81 @@ def build_models(depth, device, seed=0):
     return backbone, neck
 
 
+def conv_inventory(depth):
+    """(Cin, Cout, k, stride, Hin, Win, has_dgrad) of every conv of ResNet-`depth` + FPN(256, 5 levels) at 800x1344 —
+    SURVEY Appendix A rebuilt from the architecture (resnet.py:178-184 arch_settings, :122-155 _make_res_layer,
+    fpn.py:44-58): 61 convs for depth 50, 112 for depth 101."""
+    blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
+    convs = [(3, 64, 7, 2, H_PAD, W_PAD, False)]
+    H, W, cin = H_PAD // 4, W_PAD // 4, 64
+    for si, n in enumerate(blocks):
+        planes = 64 * 2 ** si
+        for bi in range(n):
+            s_ = 2 if (bi == 0 and si > 0) else 1
+            convs.append((cin, planes, 1, 1, H, W, True))                       # conv1
+            convs.append((planes, planes, 3, s_, H, W, True))                   # conv2 carries the stride (resnet.py:75)
+            Ho, Wo = H // s_, W // s_
+            convs.append((planes, planes * 4, 1, 1, Ho, Wo, True))              # conv3
+            if bi == 0:
+                convs.append((cin, planes * 4, 1, s_, H, W, True))              # downsample
+            cin, H, W = planes * 4, Ho, Wo
+    h, w = H_PAD // 4, W_PAD // 4
+    for li, c in enumerate((256, 512, 1024, 2048)):
+        convs.append((c, 256, 1, 1, h >> li, w >> li, True))                    # lateral
+        convs.append((256, 256, 3, 1, h >> li, w >> li, True))                  # output conv
+    return convs
+
+
+def per_layer_roofline_ms(depth, nimg):
+    """the step's time if every conv pass ran at its own roofline,
+    sum over layers and passes (forward, input gradient, weight gradient) of max(F / 2.5 PFLOP/s, bytes / 8 TB/s),
+    each tensor moved once: 16-bit activations / gradients / weights, fp32 weight gradients."""
+    tot = 0.0
+    for cin, cout, k, s_, H, W, has_dgrad in conv_inventory(depth):
+        Ho, Wo = H // s_, W // s_
+        F_ = 2.0 * nimg * Ho * Wo * cout * cin * k * k
+        x_b, y_b, w_n = nimg * H * W * cin * 2.0, nimg * Ho * Wo * cout * 2.0, cout * cin * k * k
+        passes = [x_b + y_b + w_n * 2, x_b + y_b + w_n * 4] + ([x_b + y_b + w_n * 2] if has_dgrad else [])
+        for by in passes:
+            tot += max(F_ / (MFMA_PEAK_TFLOPS * 1e12), by / 8.0e12)
+    return tot * 1e3
+
+
+def dominant_by_time():
+    """The kernel symbol with the largest share of summed kernel time in the newest committed rocprofv3 --stats
+    summary of this command (profiles/rNN_bench_kernel_stats.csv) and, where the newest PMC summary has that symbol,
+    its MFMA-pipe busy fraction.  Read from the files, never typed in here."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_stats.csv")))
+    if not files:
+        return None
+    rows = list(csv.DictReader(open(files[-1])))
+    if not rows:
+        return None
+    fam = {}
+    for r in rows:     # pool the instantiations of one kernel template by tile shape (the first template arguments)
+        name = re.sub(r"^void ", "", r["Name"]).split("(")[0]
+        fam[name] = fam.get(name, 0.0) + float(r["Percentage"])
+    name, share = max(fam.items(), key=lambda kv: kv[1])
+    out = {"symbol": name, "share": round(share / 100.0, 4), "source": os.path.relpath(files[-1], ROOT), "mfma_busy": None}
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_*.txt")))
+    for f in reversed(pmc):
+        for b in re.split(r"\n\s*\n", open(f).read()):
+            if name.split("<")[0] in b and name.split("<")[1][:12] in b:
+                m = re.search(r"MFMA[^\n]*busy[^0-9]*([0-9.]+)", b)
+                if m:
+                    out["mfma_busy"] = float(m.group(1))
+                    out["mfma_busy_source"] = os.path.relpath(f, ROOT)
+                    return out
+    return out
+
+
 class KernelTimer(object):
-    """HIP-event timing of the dominant kernel instantiation (conv_gemm_kernel<192,256,64,2,4,2,6,1>: the 3x3
-    256->256 conv GEMM at M = N*200*336 — neck.fpn_convs.0 forward and its dgrad, 2 launches per step) on the stream
-    it is launched on."""
+    """HIP-event timing of the dominant launch (the 3x3 256->256 conv GEMM at M = N*200*336 — neck.fpn_convs.0
+    forward and its dgrad, 2 launches per step; conv_halo_kernel's 256x128 tile, or conv_gemm_kernel<192,256,...> with
+    TDN_HALO=0) on the stream it is launched on."""
 
     def __init__(self, ops, match):
         self.ops, self.match, self.pairs = ops, match, []
@@ -433,10 +504,12 @@ def main():
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic if nimg == 2 else None, "traffic_source": traffic_src,
                     "algorithmic_bytes": (2 * nimg * DOM["H"] * DOM["W"] * 256 + 256 * 2304) * 2,
-                    "kernel": "conv_gemm_kernel, %dx%dx%d tile (symbol tagged for the timed launches) = 3x3 256->256 "
+                    "kernel": "%s, %dx%dx%d tile (symbol tagged for the timed launches) = 3x3 256->256 "
                               "conv GEMM, M=%d N=256 K=2304 (neck.fpn_convs.0 forward + its dgrad, 2 launches/step), "
                               "%.1f GFLOP per launch" %
-                              (plan[3], plan[4], plan[5], nimg * DOM["H"] * DOM["W"], flop / 1e9),
+                              ("conv_halo_kernel (LDS-resident %dx%d patch + halo, streamed weight ring)" %
+                               (plan[11] // 1000, plan[11] % 1000) if plan[8] >= 100 else "conv_gemm_kernel",
+                               plan[3], plan[4], plan[5], nimg * DOM["H"] * DOM["W"], flop / 1e9),
                     "avg_ms": round(ms, 4), "launches_timed": cnt, "timed_in": timed_in}
         line = {
             "metric": "images/sec ResNet-50-FPN fwd+bwd 1333x800" if args.depth == 50 else
@@ -454,6 +527,12 @@ def main():
                        "mfma_frac_whole_step": round(mfma_frac, 4),
                        "algorithmic_gflop_per_image": FWDBWD_GFLOP[args.depth]},
             "roofline": roof,
+            # the whole step against the sum of its layers' own rooflines, and what dominates by time
+            "roofline_step": {"per_layer_roofline_ms": round(per_layer_roofline_ms(args.depth, B), 4),
+                              "frac": round(per_layer_roofline_ms(args.depth, B) / (elapsed / args.steps * 1e3), 4),
+                              "note": "sum over the %d convs x (fwd, dgrad, wgrad) of max(F / 2.5 PFLOP/s, bytes / "
+                                      "8 TB/s), each tensor once" % len(conv_inventory(args.depth))},
+            "dominant_by_time": dominant_by_time(),
         }
         if ms_repack is not None:
             # the same step with every conv's BN fold + weight pack re-run inside the graph (grouped launches), i.e.

@@ -11,9 +11,19 @@ import os
 import sys
 
 ROOT = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_bench"
-WANT = ("conv_gemm_kernel<192, 256, 64, 2, 4, 2, 6, 1", "conv_gemm_kernel<128, 128, 64, 2, 4, 2, 6, 0",
-        "conv_gemm_kernel<192, 256, 64, 2, 4, 2, 6, 0", "conv_gemm_kernel<64, 64, 64, 2, 2, 2, 0, 0, 1",
-        "conv_wgrad9_group_kernel", "conv_wgrad_group_kernel<256, 64", "wgrad_finalize_group_kernel")
+import re
+
+
+def family(name):
+    """Kernel symbol without return type / argument list; template arguments kept (they name the tile)."""
+    return re.sub(r"^void ", "", name).split("(")[0]
+
+
+# tagged dominant launch first (bench.py brackets it with HIP events; TDN_TAG_DOMINANT gives it a symbol of its own:
+# conv_halo_kernel<..., 9, 0> or conv_gemm_kernel<192, 256, 64, 2, 4, 2, 6, 1, ...>), then every kernel by device time
+def is_tagged(fam):
+    return bool(re.match(r"conv_halo_kernel<.*, 9, 0>$", fam) or re.match(r"conv_gemm_kernel<192, 256, 64, 2, 4, 2, 6, 1,", fam))
+
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob(os.path.join(ROOT, "*", ""))):
@@ -22,16 +32,22 @@ for d in sorted(glob.glob(os.path.join(ROOT, "*", ""))):
         continue
     f = max(files, key=os.path.getmtime)
     for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"]
-        for w in WANT:
-            if w in n:
-                agg[w][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[family(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+
+
+def weight(fam):
+    v = agg[fam].get("GRBM_GUI_ACTIVE", [])
+    return sum(v)
+
+
+WANT = sorted(agg, key=lambda f_: (not is_tagged(f_), -weight(f_)))[:14]
 
 print("# rocprofv3 --pmc passes (separate runs per counter group, kernel-trace only) of:")
 print("#   python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph   (scripts/pmc_bench.sh)")
 print("# one MI355X, R50-FPN fwd+bwd, 2 x 3x800x1344 per step. Values are per launch (mean over launches).")
 print("# The first entry is the dominant launch (3x3 256->256, M = 134400: neck.fpn_convs.0 forward and its dgrad):")
-print("# the launches bench.py brackets with HIP events run under their own symbol (template TAG 1).")
+print("# the launches bench.py brackets with HIP events run under their own symbol (TDN_TAG_DOMINANT).  Then every")
+print("# kernel symbol by summed device time (GRBM_GUI_ACTIVE), pooled over its launches.")
 print("# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads")
 print("# (MI355X_MICROARCH.md) -> HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024.")
 for w in WANT:
@@ -39,7 +55,7 @@ for w in WANT:
     if not d:
         continue
     print()
-    print(w + "...>")
+    print(w)
     for c, v in sorted(d.items()):
         print("   %-28s mean %.6g  min %.6g  max %.6g  launches %d" % (c, sum(v) / len(v), min(v), max(v), len(v)))
     m = {c: sum(v) / len(v) for c, v in d.items()}

@@ -23,7 +23,7 @@ TOL = 1e-3
 HALO_ENV = ("TDN_HALO", "TDN_HALO_CFG3", "TDN_HALO_CFG1", "TDN_HALO_TH", "TDN_HALO_TW", "TDN_HALO_NT", "TDN_HALO_XBUF",
             "TDN_GEMM_CFG")
 # configuration ids of kHalo3 / kHalo1 (csrc/conv_halo.hip) and the output-channel multiple each needs
-CFG3 = {0: 128, 1: 128, 2: 64, 3: 64, 4: 128, 8: 128, 9: 128, 10: 64, 11: 128}
+CFG3 = {0: 128, 1: 128, 2: 64, 3: 64, 4: 128, 5: 128, 8: 128, 9: 128, 10: 64, 11: 128}
 CFG1 = {0: 128, 1: 128, 2: 64, 3: 64, 4: 128, 6: 128, 7: 256, 8: 128, 9: 128, 10: 64}
 
 
@@ -141,7 +141,7 @@ def test_halo_patch_shapes(ops, patch):
     x = det_tensor((N, Cin, H, W), 41, -1, 1)
     w = det_tensor((Cout, Cin, 3, 3), 42, -0.2, 0.2)
     ref = F.conv2d(x, w, None, 1, 1)
-    os.environ.update({"TDN_HALO_CFG3": "0", "TDN_HALO_TH": str(th), "TDN_HALO_TW": str(tw)})
+    os.environ.update({"TDN_HALO_CFG3": "5", "TDN_HALO_TH": str(th), "TDN_HALO_TW": str(tw)})
     assert uses_halo(ops, 0, N, H, W, Cin, Cout, 3, 1, 1)
     y = ops.conv2d_fwd(nhwc(x), pack_w(w), 3, 1, 1, out_f32=True)
     assert max_rel(nchw(y), ref) <= TOL
@@ -153,7 +153,7 @@ def test_halo_dilated_and_epilogue_modes(ops):
     N, H, W, C = 2, 12, 16, 128
     x = det_tensor((N, C, H, W), 51, -1, 1)
     w = det_tensor((C, C, 3, 3), 52, -0.2, 0.2)
-    os.environ["TDN_HALO_CFG3"] = "0"
+    os.environ["TDN_HALO_CFG3"] = "5"
     assert uses_halo(ops, 0, N, H, W, C, C, 3, 1, 2)
     y = ops.conv2d_fwd(nhwc(x), pack_w(w), 3, 1, 2, out_f32=True)
     assert max_rel(nchw(y), F.conv2d(x, w, None, 1, 2, 2)) <= TOL
