@@ -67,3 +67,55 @@ def test_bucketed_reducer_single_rank_rccl(use_gn):
                 assert torch.equal(p.grad, ref[id(p)]), (n, step)
     finally:
         dist.destroy_process_group()
+
+
+def test_reducer_path_gradients_vs_cpu_oracle():
+    """The gradient-sink path against the ORACLE, not against the plain HIP path: with a reducer attached (weight-
+    gradient kernels writing into the flat bucket buffer, per-producer-stream events, RCCL all-reduce of every bucket
+    on the comm stream), every weight-gradient member of the backward pass is recomputed on the CPU by
+    oracle/sched_ref.py from the GPU's own operands of that launch and compared with what sits in the bucket views
+    after ``finish()`` — bound 1e-3 (tests/parity_util.backward_in_situ), the figure of the plain path."""
+    import parity_util
+    import torch_detection_amd as T
+    from oracle import sched_ref as S
+    from torch_detection_amd import dp, functional as HF
+    dev = torch.device("cuda", 0)
+    depth = 50
+    rb, rf = T.ResNet(depth), T.FPN([256, 512, 1024, 2048], 256, 5)
+    sdb = fill_state_dict(rb.state_dict(), 50)
+    sdf = fill_state_dict(rf.state_dict(), 51)
+    rb.load_state_dict(sdb)
+    rf.load_state_dict(sdf)
+    rb.to(dev).train()
+    rf.to(dev)
+    x = det_tensor((2, 3, 96, 128), 700, -2, 2)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        red = dp.attach_reducer([rf, rb], bucket_bytes=8 << 20)
+        launches = []
+        outs = rf(rb(x.to(dev)))
+        cots = [det_tensor(tuple(o.shape), 710 + i, -1, 1).to(dev).to(o.dtype) for i, o in enumerate(outs)]
+        HF.DEBUG_BWD = launches
+        try:
+            torch.autograd.backward(outs, cots)
+            red.finish()
+            torch.cuda.synchronize()
+        finally:
+            HF.DEBUG_BWD = None
+        # the recorded (dw, dgamma, dbeta) of every member ARE views of the reducer's flat buffer
+        lo, hi = red.flat.data_ptr(), red.flat.data_ptr() + red.flat.numel() * 4
+        nw = 0
+        for rec in launches:
+            if rec[0] == 'wgrad':
+                nw += 1
+                assert all(lo <= t.data_ptr() < hi for t in rec[5] if t is not None)
+        assert nw == 61
+        sch = S.Sched(sdb, sdf, depth, 5, quant=torch.bfloat16)
+        res = parity_util.backward_in_situ(sch, rb, rf, launches, x)
+        assert res["launches"]["wgrad"] == 61 and res["launches"]["dgrad"] > 0, res["launches"]
+        for kind in ("dgrad", "dw", "dgamma", "dbeta_or_dbias"):
+            assert res[kind][0] <= parity_util.BWD_IN_SITU_TOL, (kind, res[kind])
+    finally:
+        dist.destroy_process_group()
