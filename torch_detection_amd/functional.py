@@ -897,7 +897,30 @@ def _blocks_fwd_split(blocks, cur):
     # branch whatever the capture order: the second chain starts as soon as the host has submitted the first chain's
     # nodes — a few hundred microseconds unprofiled, ~0.7 ms under rocprofv3, which is what its timelines show.)
     xs = [cur[cuts[i]:cuts[i + 1]] for i in range(ways)]
-    for b, (h1, h2, out, res) in zip(blocks, bufs):
+    # TDN_CHAIN_SYNC=n (diagnostic, default off): every n blocks each chain waits for the other chains' progress up to
+    # that block (a per-block cross-join, meant to make a replayed graph interleave the chains).  See DESIGN.md §6:
+    # hipGraphInstantiate of a capture with such joins died in round 2; kept as a knob to reproduce it with stderr.
+    chain_sync = int(os.environ.get('TDN_CHAIN_SYNC', '0'))
+    for bi_, (b, (h1, h2, out, res)) in enumerate(zip(blocks, bufs)):
+        if chain_sync > 0 and bi_ > 0 and bi_ % chain_sync == 0:
+            mode = os.environ.get('TDN_CHAIN_SYNC_MODE', 'cross')
+            if mode == 'cross':        # every chain waits for every other chain's event of this point
+                toks = [streams.record(pool[i]) for i in range(ways)]
+                for i in range(ways):
+                    for j in range(ways):
+                        if i != j:
+                            streams.wait(pool[i], toks[j])
+            elif mode == 'oneway':     # chain i waits for chain i - 1 only
+                toks = [streams.record(pool[i]) for i in range(ways)]
+                for i in range(1, ways):
+                    streams.wait(pool[i], toks[i - 1])
+            else:                      # 'main': join into the main stream and fork again
+                main_ = torch.cuda.current_stream(dev)
+                for i in range(ways):
+                    streams.wait_stream(main_, pool[i])
+                ev_ = streams.record(main_)
+                for i in range(ways):
+                    streams.wait(pool[i], ev_)
         for i in range(ways):
             a, e_ = cuts[i], cuts[i + 1]
             prev = _lib.set_stream_override(pool[i].cuda_stream)

@@ -108,6 +108,8 @@ class GraphedStep(object):
             # thread_local: other threads (the process group's watchdog, the allocator's helpers) are not policed
             # during the capture; the launches autograd's device thread makes into the capturing streams are captured
             # either way
+            from . import streams
+            streams.capture_started()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
             self.graph = g
