@@ -4,6 +4,9 @@ SURVEY Appendix A at per-GPU batch B.  Prints TFLOP/s per (shape, config) and ch
 config 0 bit for bit (same K order => identical results; a mismatch means a pipeline race)."""
 import argparse
 import os
+
+# alternate tiles / ablation and cycle-stamp builds live in libtdn_trace.so (make -C torch_detection_amd/csrc TRACE=1)
+os.environ.setdefault("TDN_LIB", "libtdn_trace.so")
 import sys
 
 import torch

@@ -2,6 +2,9 @@
 """Timing-only ablations of the halo kernel (library built with `make ABL=1`): full kernel vs no MFMA (1) vs no
 LDS-DMA in the K loop (2) vs no fragment reads (3), configurations 0 (128x128, 4 waves) and 1 (256x128, 8 waves)."""
 import os
+
+# alternate tiles / ablation and cycle-stamp builds live in libtdn_trace.so (make -C torch_detection_amd/csrc TRACE=1)
+os.environ.setdefault("TDN_LIB", "libtdn_trace.so")
 import sys
 
 import torch

@@ -4,6 +4,9 @@ per workgroup population, the shader-clock cost of set-up, prologue issue, first
 loop tail and epilogue, plus the launch ramp (spread of workgroup start / end stamps)."""
 import argparse
 import os
+
+# alternate tiles / ablation and cycle-stamp builds live in libtdn_trace.so (make -C torch_detection_amd/csrc TRACE=1)
+os.environ.setdefault("TDN_LIB", "libtdn_trace.so")
 import sys
 
 import numpy as np

@@ -10,7 +10,9 @@ import threading
 import torch  # noqa: F401  (loads the HIP runtime first so libtdn binds to the same libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtdn.so")
+# TDN_LIB: another build of the library in the package directory — scripts/ use libtdn_trace.so (`make TRACE=1`: ablation
+# and cycle-stamp instantiations) for their sweeps; the package, the tests and bench.py use the product, libtdn.so
+LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("TDN_LIB", "") or "libtdn.so"))
 
 TDN_BF16 = 0
 TDN_F16 = 1

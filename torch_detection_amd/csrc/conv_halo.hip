@@ -794,7 +794,7 @@ static int halo_run(HaloParams& p, const HaloShape& s, const HaloPlan& pl, int d
     for (int t = 0; t < 9; ++t)
       TDN_CHECK(((p.taps[t] >> 8) & 0xff) == ((p.taps[t % 3] >> 8) & 0xff) && (p.taps[t] >> 16) == t,
                 "halo plan: taps are not (kh, kw) ordered");
-#ifdef TDN_HALO_ABLATIONS   // timing-only builds of two configurations (make ABL=1): wrong results by construction
+#ifdef TDN_TRACE_BUILD   // timing-only ablation builds of two configurations (make TRACE=1): wrong results by construction
     if (const int abl = halo_env_int("TDN_HALO_ABL", 0)) {
       if (pl.cfg == 0 && abl == 1) return halo_launch<4, 4, 2, 2, 7, 9, 2, false, 1>(p, pl.lds, stream);
       if (pl.cfg == 0 && abl == 2) return halo_launch<4, 4, 2, 2, 7, 9, 2, false, 2>(p, pl.lds, stream);

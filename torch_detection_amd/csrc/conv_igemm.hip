@@ -288,6 +288,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     }
   };
 
+#ifdef TDN_TRACE_BUILD   // alternate load paths of the ablation builds (libtdn_trace.so)
   // ABLATION (MODE 10, timing only): the same K-step fetched with buffer_load_dwordx4 ... offen lds — a descriptor
   // per operand whose base carries the wave-uniform part (tap displacement, channel chunk), a 32-bit per-lane offset,
   // and the hardware range check instead of the zero page for out-of-image taps
@@ -359,6 +360,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     for (int it = 0; it < B_IT; ++it) *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(sB + it * (RPI * NW * ROWB)) = rb[it];
   };
 
+#endif
+
   // ---- fragment reader constants ----
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
@@ -422,6 +425,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
         stage_load(fill);
 #pragma unroll
         for (int kk = 0; kk < KSUB; ++kk) mfma_substep(sA, sB, kk);
+#ifdef TDN_TRACE_BUILD
       } else if constexpr (MODE == 3) {   // ABLATION (timing only, wrong results): no loads in the K loop
 #pragma unroll
         for (int kk = 0; kk < KSUB; ++kk) mfma_substep(sA, sB, kk);
@@ -486,6 +490,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
             asm volatile("" ::"v"(v));
           }
         }
+#endif
       } else if constexpr (MODE == 6) {
         // software-pipelined fragments: sub-step 1's LDS reads are issued between sub-step 0's MFMAs (second
         // register set), so only ONE LDS latency per K-step is exposed; the interleave is pinned with
@@ -795,7 +800,10 @@ static inline void class_divisors(GemmClass& c) {
   fast_div_init((unsigned)c.Wa, &c.mul_w, &c.shr_w);
 }
 
-// Tile configurations. LDS = NSTAGE * (BM + BN) * BK * 2 bytes.  MODE 0: LDS-DMA of the next K-step right after the
+// Tile configurations. LDS = NSTAGE * (BM + BN) * BK * 2 bytes.  The production library (libtdn.so) instantiates ids
+// 0, 1, 2, 3, 25 and 46 (plus the tagged twin of 3 and the stem's 128x64x32) — the set choose_cfg picks from; every
+// other row (alternates of the round-1/2 sweeps, timing-only ablation MODEs, TAG-2 cycle-stamp builds) exists only in
+// libtdn_trace.so (`make TRACE=1`, loaded by the scripts with TDN_LIB=libtdn_trace.so).  One source, one ISA.  MODE 0: LDS-DMA of the next K-step right after the
 // barrier, fragments read per sub-step; MODE 6: fragment reads software-pipelined under the MFMAs; MODE 3/4/7/8:
 // timing-only ablations (wrong results); tag 2: cycle-stamp tracing build (tdn_debug_trace, scripts/trace_gemm.py).
 struct GemmCfg { int bm, bn, bk, wm, wn, nstage, mode, tag, kg = 1; };
@@ -943,7 +951,12 @@ static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0, int ktap 
   if (grouped) return 0;   // block-diagonal grouped conv: one 64-channel block per N tile
   if (const char* env = getenv("TDN_GEMM_CFG")) {
     const int id = atoi(env);
-    if (id >= 0 && id < kNumCfgs && ngemm % kCfgs[id].bn == 0 && ktap % kCfgs[id].bk == 0) return id;
+#ifdef TDN_TRACE_BUILD
+    const bool built = true;
+#else
+    const bool built = id == 0 || id == 1 || id == 2 || id == 3 || id == 25 || id == 46;   // production tiles
+#endif
+    if (id >= 0 && id < kNumCfgs && built && ngemm % kCfgs[id].bn == 0 && ktap % kCfgs[id].bk == 0) return id;
   }
   // Measured on MI355X over the R50-FPN shapes (scripts/conv_bench.py; profiles/convbench_*.log): several small
   // co-resident workgroups per CU (64-pixel tiles, 2-deep ring, 32-48 KB LDS) beat one large deeply pipelined
@@ -1065,6 +1078,9 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
       if (maxM >= 100000 && p.Cout == 256 && p.cls[0].ntaps * p.Ktap == 2304 && getenv("TDN_TAG_DOMINANT"))
         return launch_gemm<192, 256, 64, 2, 4, 2, 6, 1>(p, maxM, stream);
       return launch_gemm<192, 256, 64, 2, 4, 2, 6>(p, maxM, stream);
+    case 25: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 2>(p, maxM, stream);
+    case 46: return launch_gemm<128, 128, 64, 2, 4, 2, 6, 0>(p, maxM, stream);
+#ifdef TDN_TRACE_BUILD   // alternates, ablations and cycle-stamp builds: libtdn_trace.so only (make TRACE=1)
     case 4: return launch_gemm<64, 128, 64, 2, 2, 2, 0>(p, maxM, stream);
     case 5: return launch_gemm<64, 128, 64, 2, 2, 3, 0>(p, maxM, stream);
     case 6: return launch_gemm<64, 64, 64, 2, 2, 4, 0>(p, maxM, stream);
@@ -1086,7 +1102,6 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
     case 22: return launch_gemm<64, 64, 64, 2, 2, 2, 3, 2>(p, maxM, stream);
     case 23: return launch_gemm<64, 64, 64, 2, 2, 4, 3, 2>(p, maxM, stream);
     case 24: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 4>(p, maxM, stream);
-    case 25: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 2>(p, maxM, stream);
     case 26: return launch_gemm<64, 128, 64, 2, 2, 2, 6, 0, 2>(p, maxM, stream);
     case 27: return launch_gemm<64, 128, 64, 2, 2, 2, 0, 0, 2>(p, maxM, stream);
     case 28: return launch_gemm<128, 128, 64, 2, 2, 2, 6, 0, 2>(p, maxM, stream);
@@ -1107,7 +1122,6 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
     case 43: return launch_gemm<128, 128, 64, 2, 4, 2, 6, 2>(p, maxM, stream);
     case 44: return launch_gemm<64, 128, 64, 2, 4, 2, 6, 0>(p, maxM, stream);
     case 45: return launch_gemm<64, 64, 64, 2, 4, 2, 0, 0>(p, maxM, stream);
-    case 46: return launch_gemm<128, 128, 64, 2, 4, 2, 6, 0>(p, maxM, stream);
     case 47: return launch_gemm<64, 64, 64, 2, 2, 2, 10, 2>(p, maxM, stream);
     case 48: return launch_gemm<64, 64, 64, 2, 2, 4, 10, 2>(p, maxM, stream);
     case 49: return launch_gemm<192, 256, 64, 2, 4, 2, 10, 2>(p, maxM, stream);
@@ -1124,6 +1138,7 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
     case 60: return launch_gemm<128, 64, 64, 2, 2, 2, 6, 0>(p, maxM, stream);
     case 61: return launch_gemm<256, 64, 64, 4, 2, 3, 6, 0>(p, maxM, stream);
     case 62: return launch_gemm<128, 64, 64, 2, 2, 3, 6, 0>(p, maxM, stream);
+#endif
     default: TDN_CHECK(false, "bad GEMM config id"); return -1;
   }
 }
