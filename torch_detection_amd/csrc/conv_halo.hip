@@ -590,6 +590,9 @@ static const HaloCfg kHalo1[] = {
     {2, 4, 2, 2, 6, 1, 4},   // 9   64 x 128, 4 consumer + 4 loader waves
     {4, 2, 2, 2, 5, 1, 4},   // 10 128 x  64, 4 consumer + 4 loader waves
     {4, 4, 2, 2, 3, 1, 4},   // 11 configuration 8 with the shallow ring
+    {4, 2, 2, 2, 5, 1, 8},   // 12 128 x  64, 4 consumer + 8 loader waves
+    {2, 4, 2, 2, 6, 1, 8},   // 13  64 x 128, 4 consumer + 8 loader waves
+    {2, 2, 2, 2, 6, 1, 8},   // 14  64 x  64, 4 consumer + 8 loader waves (wave tile 32 x 32)
 };
 static const int kNumHalo3 = (int)(sizeof(kHalo3) / sizeof(kHalo3[0]));
 static const int kNumHalo1 = (int)(sizeof(kHalo1) / sizeof(kHalo1[0]));
@@ -747,6 +750,9 @@ static int halo_dispatch1(int cfg, const HaloParams& p, size_t lds, hipStream_t 
     case 9: return halo_launch<2, 4, 2, 2, 6, 1, 1, F16, 0, 4>(p, lds, stream);
     case 10: return halo_launch<4, 2, 2, 2, 5, 1, 1, F16, 0, 4>(p, lds, stream);
     case 11: return halo_launch<4, 4, 2, 2, 3, 1, 1, F16, 0, 4>(p, lds, stream);
+    case 12: return halo_launch<4, 2, 2, 2, 5, 1, 1, F16, 0, 8>(p, lds, stream);
+    case 13: return halo_launch<2, 4, 2, 2, 6, 1, 1, F16, 0, 8>(p, lds, stream);
+    case 14: return halo_launch<2, 2, 2, 2, 6, 1, 1, F16, 0, 8>(p, lds, stream);
     default: TDN_CHECK(false, "bad 1x1 halo config %d", cfg); return -1;
   }
 }
