@@ -576,6 +576,9 @@ static const HaloCfg kHalo3[] = {
     {4, 2, 2, 2, 5, 1, 4},   // 10 128 x  64, 4 consumer + 4 loader waves
     {4, 4, 2, 2, 4, 1, 4},   // 11 configuration 8 with a 4-deep ring
     {4, 4, 4, 2, 4, 2, 4},   // 12 256 x 128, 8 consumer + 4 loader waves (3 waves per SIMD: <= 168 registers)
+    {4, 2, 2, 4, 4, 1, 8},   // 13 128 x 128, 8 consumer (wave tile 64 x 32) + 8 loader waves: <= 128 registers
+    {4, 2, 2, 4, 4, 1, 4},   // 14 128 x 128, 8 consumer (wave tile 64 x 32) + 4 loader waves: <= 168 registers
+    {2, 4, 4, 2, 4, 1, 4},   // 15 128 x 128, 8 consumer (wave tile 32 x 64) + 4 loader waves
 };
 static const HaloCfg kHalo1[] = {
     {4, 4, 2, 2, 5, 1},   // 0  128 x 128, 4 waves
@@ -732,6 +735,9 @@ static int halo_dispatch3(int cfg, const HaloParams& p, size_t lds, hipStream_t 
     case 10: return halo_launch<4, 2, 2, 2, 5, 9, 1, F16, 0, 4>(p, lds, stream);
     case 11: return halo_launch<4, 4, 2, 2, 4, 9, 1, F16, 0, 4>(p, lds, stream);
     case 12: return halo_launch<4, 4, 4, 2, 4, 9, 2, F16, 0, 4>(p, lds, stream);
+    case 13: return halo_launch<4, 2, 2, 4, 4, 9, 1, F16, 0, 8>(p, lds, stream);
+    case 14: return halo_launch<4, 2, 2, 4, 4, 9, 1, F16, 0, 4>(p, lds, stream);
+    case 15: return halo_launch<2, 4, 4, 2, 4, 9, 1, F16, 0, 4>(p, lds, stream);
     default: TDN_CHECK(false, "bad 3x3 halo config %d", cfg); return -1;
   }
 }
@@ -805,6 +811,9 @@ static int halo_run(HaloParams& p, const HaloShape& s, const HaloPlan& pl, int d
       if (pl.cfg == 0 && abl == 1) return halo_launch<4, 4, 2, 2, 7, 9, 2, false, 1>(p, pl.lds, stream);
       if (pl.cfg == 0 && abl == 2) return halo_launch<4, 4, 2, 2, 7, 9, 2, false, 2>(p, pl.lds, stream);
       if (pl.cfg == 0 && abl == 3) return halo_launch<4, 4, 2, 2, 7, 9, 2, false, 3>(p, pl.lds, stream);
+      if (pl.cfg == 11 && abl == 1) return halo_launch<4, 4, 2, 2, 4, 9, 1, false, 1, 4>(p, pl.lds, stream);
+      if (pl.cfg == 11 && abl == 2) return halo_launch<4, 4, 2, 2, 4, 9, 1, false, 2, 4>(p, pl.lds, stream);
+      if (pl.cfg == 11 && abl == 3) return halo_launch<4, 4, 2, 2, 4, 9, 1, false, 3, 4>(p, pl.lds, stream);
       if (pl.cfg == 1 && abl == 1) return halo_launch<4, 4, 4, 2, 4, 9, 1, false, 1>(p, pl.lds, stream);
       if (pl.cfg == 1 && abl == 2) return halo_launch<4, 4, 4, 2, 4, 9, 1, false, 2>(p, pl.lds, stream);
       if (pl.cfg == 1 && abl == 3) return halo_launch<4, 4, 4, 2, 4, 9, 1, false, 3>(p, pl.lds, stream);
