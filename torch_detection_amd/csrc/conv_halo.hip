@@ -644,6 +644,7 @@ static int halo_mode() { return halo_env_int("TDN_HALO", 3); }
 // Choose configuration, patch, residency.  Returns false when the halo kernel does not apply.
 static bool halo_make_plan(const HaloShape& s, HaloPlan* pl) {
   if (halo_mode() == 0) return false;
+  if (halo_env_int("TDN_SPLITK", 0) != 0) return false;   // the opt-in cross-workgroup split-K lives in the generic kernel
   if (s.Cin % 64 != 0 || s.Cout % 64 != 0) return false;
   if (s.k == 3 && (s.sa != 1 || s.halo > 2)) return false;
   if (s.k == 3 && !(halo_mode() & 1)) return false;
