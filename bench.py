@@ -129,8 +129,9 @@ def dominant_by_time():
     pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_*.txt")))
     for f in reversed(pmc):
         for b in re.split(r"\n\s*\n", open(f).read()):
-            if name.split("<")[0] in b and name.split("<")[1][:12] in b:
-                m = re.search(r"MFMA[^\n]*busy[^0-9]*([0-9.]+)", b)
+            head = b.strip().split("\n")[0].strip()
+            if head and not head.startswith("#") and head.rstrip(".>") and name.startswith(head.rstrip(".>")):
+                m = re.search(r"MFMA pipe utilisation: ([0-9.]+)", b)
                 if m:
                     out["mfma_busy"] = float(m.group(1))
                     out["mfma_busy_source"] = os.path.relpath(f, ROOT)

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from torch_detection_amd import ops  # noqa: E402
-from halo_ablate import graph_time  # noqa: E402
+from halo_ablate import graph_time  # noqa: E402  (imports only: halo_ablate guards its main)
 
 
 def main():
