@@ -66,9 +66,11 @@ class GradReducer(object):
                 cur_start, cur_slots = end, 0
         self.use_streams = self.device.type == 'cuda'
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_streams else None
-        # RCCL divides inside the collective (ReduceOp.AVG): no extra pass over the 107 MB buffer in finish(); gloo
-        # has no AVG, and integer-free 16-bit wire sums are averaged while they are widened back to fp32
-        self._avg_in_collective = bool(self.enabled and self.average and self.world > 1 and self.use_streams and
+        # RCCL divides inside the collective (ReduceOp.AVG): no extra pass over the 107 MB buffer in finish().  gloo has
+        # no AVG, and 16-bit wire sums are averaged while they are widened back to fp32.  Also taken with ONE rank (AVG
+        # over one rank is the identity): the single-rank RCCL tests and `bench.py --force-reducer` then run exactly the
+        # collective the 8-GPU step captures.
+        self._avg_in_collective = bool(self.enabled and self.average and self.use_streams and
                                        self.comm_dtype is None and dist.get_backend(group) == 'nccl')
         self._pending = None
         self._works = []
