@@ -101,6 +101,29 @@ __device__ __forceinline__ void wg_wait_vm_and_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+#ifdef TDN_TRACE_BUILD
+// libtdn_trace.so only (scripts/wgrad_stamps.py): 8 x 8-byte stamps per workgroup of the tap-per-tile kernel — cycle
+// counter at entry / first data landed / loop end / stores issued, the 100 MHz wall clock at entry and exit, the number
+// of K-steps, and the hardware id (XCC, SE, CU) the workgroup ran on.
+__device__ unsigned long long* g_wg_trace = nullptr;
+__device__ int g_wg_trace_cap = 0;
+#define WG_STAMP(slot, val)                                                                        \
+  do {                                                                                             \
+    if (g_wg_trace && tid == 0 && (int)blockIdx.x < g_wg_trace_cap)                                \
+      g_wg_trace[(size_t)blockIdx.x * 8 + (slot)] = (unsigned long long)(val);                     \
+  } while (0)
+extern "C" int tdn_debug_wgrad_trace(void* buf, int nwg_cap) {
+  unsigned long long* b = (unsigned long long*)buf;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), &b, sizeof(b));
+  TDN_CHECK(e == hipSuccess, "tdn_debug_wgrad_trace: %s", hipGetErrorString(e));
+  e = hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace_cap), &nwg_cap, sizeof(nwg_cap));
+  TDN_CHECK(e == hipSuccess, "tdn_debug_wgrad_trace: %s", hipGetErrorString(e));
+  return 0;
+}
+#else
+#define WG_STAMP(slot, val) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // One tap per tile: a workgroup owns BMW (co) x BNW (ci of one tap) of one member for one pixel split.
 // NST-deep LDS ring filled by LDS-DMA: while K-step t is multiplied the loads of steps t+1 .. t+NST-2 stay in
@@ -136,6 +159,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_group_kernel(const Wg
   const int ntiles = p.tiles_co * p.tiles_k;
   int split, tile;
   if (!wg_work((int)blockIdx.x - grp.blk_start[idx], p.splitk, ntiles, split, tile)) return;
+  WG_STAMP(0, __builtin_readcyclecounter());
+  WG_STAMP(4, __builtin_amdgcn_s_memrealtime());
   const int tile_co = tile % p.tiles_co, tile_k = tile / p.tiles_co;
   const int co0 = tile_co * BMW;
   const int kt_per_tap = p.Ktap / BNW;
@@ -238,6 +263,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_group_kernel(const Wg
     int slot = 0, fill = NST - 1;
     for (int t = 0; t < T; ++t) {
       wg_wait_vm_and_barrier<LOADS * (NST - 2)>();   // K-step t has landed for every wave; slot (t-1) is free
+      if (t == 0) WG_STAMP(1, __builtin_readcyclecounter());
       stage_load(m_begin + (t + NST - 1) * BKW, fill);
       const char* sG = smem + slot * STAGE;
       const char* sX = sG + G_BYTES;
@@ -275,6 +301,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_group_kernel(const Wg
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail loads still target the ring
   }
+  WG_STAMP(2, __builtin_readcyclecounter());
+  WG_STAMP(6, ((unsigned long long)T << 32) | (unsigned)idx);
 
   // ---- store: lane holds ci = ci_base + 4*grp4 .. +3 for co = co_base + (lane&15) ----
   const int fr = lane & 15;
@@ -291,6 +319,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_group_kernel(const Wg
       }
       if (do_colsum && grp4 == 0) p.colsum[(int64_t)split * Cout + co] = acc1[i][0];
     }
+#ifdef TDN_TRACE_BUILD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_STAMP(3, __builtin_readcyclecounter());
+    WG_STAMP(5, __builtin_amdgcn_s_memrealtime());
+    WG_STAMP(7, (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |        // HW_ID
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32));  // XCC_ID
+#endif
     return;
   }
   // ---- direct member (one split): the gradient itself, BN scale folded, + this tile's share of sum_k w * G ----
