@@ -245,6 +245,13 @@ int tdn_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int
 int tdn_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, const void* mask_src, void* dx, int N,
                          int H, int W, int C, int dtype, void* stream);
 
+/* The same adjoint of ReLU -> maxpool (resnet.py:257-258) with the ReLU mask taken from the pool's OUTPUT
+ * y_pooled[N][Ho][Wo][C] instead of its full-size input: a window's value is the value of the element it
+ * selected, so the gradient of a window passes where y_pooled > 0.  Same dx bit for bit; reads a tensor a
+ * quarter of the size, and the stem's activation need not be kept for backward. */
+int tdn_maxpool3x3s2_relu_bwd(const void* dy, const uint8_t* idx, const void* y_pooled, void* dx, int N,
+                              int H, int W, int C, int dtype, void* stream);
+
 /* F.max_pool2d(x, 1, stride=2) (fpn.py:116): y[N][ceil(H/2)][ceil(W/2)][C] = x[:, ::2, ::2, :]. */
 int tdn_subsample2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype,
                        void* stream);

@@ -235,6 +235,11 @@ def test_maxpool(ops, shape):
     # fused ReLU mask of the stem output
     dxm = ops.maxpool3x3s2_bwd(nhwc(dy), idx, (H, W), nhwc(x.detach()))
     assert max_rel(nchw(dxm), x.grad * (x.detach() > 0).float()) <= 2 ** -7
+    # the same mask read from the pool's output (what the backbone's backward pass uses): identical bit for bit
+    dxp = ops.maxpool3x3s2_bwd(nhwc(dy), idx, (H, W), pooled=yg)
+    assert torch.equal(dxp, dxm)
+    with pytest.raises(RuntimeError):
+        ops.maxpool3x3s2_bwd(nhwc(dy), idx, (H, W), nhwc(x.detach()), pooled=yg)
 
 
 def test_subsample_and_mask(ops):

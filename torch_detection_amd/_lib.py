@@ -110,6 +110,7 @@ SIGNATURES = {
     "tdn_stem_conv_wgrad": (c_int, [c_void_p] * 9 + [c_float] + [c_int] * 4 + [c_void_p, c_i64, c_int, c_void_p]),
     "tdn_maxpool3x3s2_fwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "tdn_maxpool3x3s2_bwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "tdn_maxpool3x3s2_relu_bwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "tdn_subsample2_fwd": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "tdn_subsample2_bwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "tdn_add_relu_mask": (c_int, [c_void_p] * 4 + [c_i64, c_int, c_void_p]),

@@ -389,9 +389,12 @@ extern "C" int tdn_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N,
 }
 
 // Gather form of the adjoint: each input element sums dy of the (<= 4) windows that selected it.
+// ReLU in front of the pool: `mask` is the pool's full-size input (gradient passes where it is > 0), or `ypool` is the
+// pool's OUTPUT — a window's value is the value of the element it selected, so "selected element > 0" can be read
+// from the 4x smaller tensor (same result bit for bit: all windows that selected one element carry its value).
 template <bool F16>
-__global__ void maxpool_bwd_kernel(const bf16_t* dy, const uint8_t* idx, const bf16_t* mask, bf16_t* dx, int N, int H,
-                                   int W, int C, int Ho, int Wo) {
+__global__ void maxpool_bwd_kernel(const bf16_t* dy, const uint8_t* idx, const bf16_t* mask, const bf16_t* ypool,
+                                   bf16_t* dx, int N, int H, int W, int C, int Ho, int Wo) {
   const int C8 = C >> 3;
   const int64_t total = (int64_t)N * H * W * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -415,9 +418,16 @@ __global__ void maxpool_bwd_kernel(const bf16_t* dy, const uint8_t* idx, const b
         const int64_t o = ((((int64_t)n * Ho + ho) * Wo + wo) * C8 + c8) * 8;
         const uint64_t pk = *(const uint64_t*)(idx + o);
         const bf16x8_t g = *(const bf16x8_t*)(dy + o);
+        if (ypool) {
+          const bf16x8_t yv = *(const bf16x8_t*)(ypool + o);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if ((int)((pk >> (8 * e)) & 0xff) == code) acc[e] += elem_to_f32<F16>(g[e]);
+          for (int e = 0; e < 8; ++e)
+            if ((int)((pk >> (8 * e)) & 0xff) == code && elem_to_f32<F16>(yv[e]) > 0.f) acc[e] += elem_to_f32<F16>(g[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if ((int)((pk >> (8 * e)) & 0xff) == code) acc[e] += elem_to_f32<F16>(g[e]);
+        }
       }
     }
     bf16x8_t o8;
@@ -440,7 +450,22 @@ extern "C" int tdn_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, const vo
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int64_t total = (int64_t)N * H * W * (C / 8);
   TDN_LAUNCH_T(maxpool_bwd_kernel, dtype, dim3(grid_for(total, 256)), dim3(256), (hipStream_t)stream,
-                     (const bf16_t*)dy, idx, (const bf16_t*)mask_src, (bf16_t*)dx, N, H, W, C, Ho, Wo);
+                     (const bf16_t*)dy, idx, (const bf16_t*)mask_src, (const bf16_t*)nullptr, (bf16_t*)dx, N, H, W, C, Ho,
+                     Wo);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tdn_maxpool3x3s2_relu_bwd(const void* dy, const uint8_t* idx, const void* y_pooled, void* dx, int N,
+                                         int H, int W, int C, int dtype, void* stream) {
+  TDN_CHECK_DTYPE(dtype);
+  TDN_CHECK(dy && idx && y_pooled && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0,
+            "tdn_maxpool3x3s2_relu_bwd: bad arguments");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)N * H * W * (C / 8);
+  TDN_LAUNCH_T(maxpool_bwd_kernel, dtype, dim3(grid_for(total, 256)), dim3(256), (hipStream_t)stream,
+                     (const bf16_t*)dy, idx, (const bf16_t*)nullptr, (const bf16_t*)y_pooled, (bf16_t*)dx, N, H, W, C, Ho,
+                     Wo);
   TDN_LAUNCH_CHECK();
   return 0;
 }

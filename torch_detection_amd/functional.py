@@ -1041,13 +1041,14 @@ class SeqNetFunction(torch.autograd.Function):
     @staticmethod
     def _forward(ctx, net, x, *params):
         st = {}
+        s = None
         if net.stem is not None and isinstance(x, StagedImages):
             if x.dtype != net.dtype:
                 raise RuntimeError('staged images are %s but the net computes in %s' % (x.dtype, net.dtype))
             xp, (H, W) = x.xp, x.hw
             s = _stem_fwd(net.stem, xp, (H, W))
             cur, idx = ops.maxpool3x3s2_fwd(s)
-            st.update(xp=xp, s=s, idx=idx, img_hw=(H, W))
+            st.update(xp=xp, y=cur, idx=idx, img_hw=(H, W))   # the stem's own output is not kept: see maxpool3x3s2_bwd
         elif net.stem is not None:
             if x.dim() != 4 or x.shape[1] != 3:
                 raise RuntimeError('ResNet expects an (N,3,H,W) image batch, got %s' % (tuple(x.shape),))
@@ -1056,7 +1057,7 @@ class SeqNetFunction(torch.autograd.Function):
             xp = ops.stage_image(img, net.dtype)
             s = _stem_fwd(net.stem, xp, (H, W))
             cur, idx = ops.maxpool3x3s2_fwd(s)
-            st.update(xp=xp, s=s, idx=idx, img_hw=(H, W))
+            st.update(xp=xp, y=cur, idx=idx, img_hw=(H, W))   # the stem's own output is not kept: see maxpool3x3s2_bwd
         else:
             cur = ops.to_nhwc_bf16(x, net.dtype)
         saved, outs = [], []
@@ -1086,8 +1087,8 @@ class SeqNetFunction(torch.autograd.Function):
             outs.append(cur)
         join_branches(cur.device)
         ctx.net, ctx.st, ctx.saved, ctx.dev = net, st, saved, cur.device
-        if DEBUG_CAPTURE is not None:
-            DEBUG_CAPTURE['seq'] = (st, saved)
+        if DEBUG_CAPTURE is not None:      # parity tests look at the stem's activation too; the step itself drops it
+            DEBUG_CAPTURE['seq'] = (dict(st, s=s), saved)
         return tuple(_as_nchw(o) for o in outs)
 
     @staticmethod
@@ -1176,7 +1177,7 @@ class SeqNetFunction(torch.autograd.Function):
         if net.stem is not None:
             if g is not None:
                 H, W = st['img_hw']
-                ds = ops.maxpool3x3s2_bwd(g, st['idx'], (H // 2, W // 2), st['s'])
+                ds = ops.maxpool3x3s2_bwd(g, st['idx'], (H // 2, W // 2), pooled=st['y'])
                 unit_grads[net.stem] = unit_wgrad(net.stem, st['xp'], ds, (H, W), queue=wq)
             # the image itself gets no gradient (the reference never needs one; SURVEY §8(d): -5.06 GFLOP)
         elif need_net_dx and g is not None:

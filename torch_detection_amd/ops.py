@@ -435,17 +435,29 @@ def maxpool3x3s2_fwd(x):
     return y, idx
 
 
-def maxpool3x3s2_bwd(dy, idx, in_hw, mask_src=None):
+def maxpool3x3s2_bwd(dy, idx, in_hw, mask_src=None, pooled=None):
+    """Adjoint of MaxPool2d(3, 2, 1); with a ReLU in front of the pool either ``mask_src`` (the pool's input) or
+    ``pooled`` (the pool's output — same result, a quarter of the bytes) supplies the ReLU mask."""
     _chk_act(dy, "dy")
     N, Ho, Wo, C = dy.shape
     H, W = in_hw
     if (Ho, Wo) != (conv_out_size(H, 3, 2, 1), conv_out_size(W, 3, 2, 1)) or tuple(idx.shape) != tuple(dy.shape):
         raise RuntimeError("maxpool bwd: inconsistent shapes")
+    if mask_src is not None and pooled is not None:
+        raise RuntimeError("maxpool bwd: give mask_src or pooled, not both")
     if mask_src is not None:
         _chk_act(mask_src, "mask_src", C, dy.dtype)
         if tuple(mask_src.shape) != (N, H, W, C):
             raise RuntimeError("maxpool bwd: mask_src shape mismatch")
     dx = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
+    if pooled is not None:
+        _chk_act(pooled, "pooled", C, dy.dtype)
+        if tuple(pooled.shape) != tuple(dy.shape):
+            raise RuntimeError("maxpool bwd: pooled shape mismatch")
+        _lib.check(_lib.load().tdn_maxpool3x3s2_relu_bwd(_ptr(dy), _ptr(idx), _ptr(pooled), _ptr(dx), N, H, W, C,
+                                                         dtype_code(dy.dtype), _lib.stream_ptr()),
+                   "tdn_maxpool3x3s2_relu_bwd")
+        return dx
     _lib.check(_lib.load().tdn_maxpool3x3s2_bwd(_ptr(dy), _ptr(idx), _ptr(mask_src), _ptr(dx), N, H, W, C,
                                                 dtype_code(dy.dtype), _lib.stream_ptr()), "tdn_maxpool3x3s2_bwd")
     return dx
