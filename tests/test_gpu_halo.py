@@ -128,6 +128,7 @@ def test_halo_default_shapes_take_the_kernel(ops):
     assert not uses_halo(ops, 0, 2, 200, 336, 64, 64, 3, 1, 1)       # layer1: 64 output channels
     assert not uses_halo(ops, 0, 2, 100, 168, 128, 128, 3, 2, 1)     # stride 2
     assert not uses_halo(ops, 0, 2, 50, 84, 256, 1024, 1, 1, 0)      # 1x1 layers stay with the generic kernel
+    assert not uses_halo(ops, 0, 2, 25, 42, 256, 256, 3, 1, 1)       # fpn_convs.3: too few pixels at 256 channels
     os.environ["TDN_HALO"] = "0"
     assert not uses_halo(ops, 0, 2, 50, 84, 256, 256, 3, 1, 1)
 

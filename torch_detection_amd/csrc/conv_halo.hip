@@ -660,7 +660,8 @@ static bool halo_make_plan(const HaloShape& s, HaloPlan* pl) {
   if (s.k == 3 && s.Cout % 128 == 0) {
     if (M >= 100000) cfg = 1;                       // fpn_convs.0 and its dgrad
     else if (M >= 6000 && M < 30000) cfg = 11;      // layer2 per image, layer3 / P4 per batch: 128 x 128, 4 + 4 waves
-    else if (M < 6000 && s.Cin >= 256) cfg = 10;    // layer3 / layer4 per image: 128 x 64, 4 + 4 waves
+    else if (M < 6000 && s.Cin >= 256 && (s.Cin >= 512 || M >= 3000))
+      cfg = 10;   // layer3 / layer4 per image: 128 x 64, 4 + 4 waves (P5's 256-channel conv, M = 2,100: generic 13 vs 16 us)
   }
   cfg = halo_env_int(s.k == 3 ? "TDN_HALO_CFG3" : "TDN_HALO_CFG1", cfg);
   if (cfg < 0 || cfg >= (s.k == 3 ? kNumHalo3 : kNumHalo1)) return false;   // (-1: not taken)
