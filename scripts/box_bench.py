@@ -89,7 +89,10 @@ def main():
     y, idx = ops.maxpool3x3s2_fwd(x)
     dy = torch.randn_like(y)
     t = timeit(lambda: ops.maxpool3x3s2_bwd(dy, idx, (400, 672), x))
-    report("maxpool3x3s2_bwd (+ ReLU mask)", t, dy.numel() * 3 + x.numel() * 4)
+    report("maxpool3x3s2_bwd (+ ReLU mask from the pool's input)", t, dy.numel() * 3 + x.numel() * 4)
+    t = timeit(lambda: ops.maxpool3x3s2_bwd(dy, idx, (400, 672), pooled=y))
+    report("maxpool3x3s2_bwd (+ ReLU mask from the pool's output: what the backbone uses)", t,
+           dy.numel() * 5 + x.numel() * 2)
     z = torch.randn(2, 200, 336, 256, device=dev).bfloat16()
     gam, bet = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev)
     t = timeit(lambda: ops.gn_fwd(z, gam, bet, 32, 1e-5, z, True))

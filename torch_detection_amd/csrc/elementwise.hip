@@ -5,6 +5,45 @@
 #include <limits.h>
 #include <string.h>
 
+// Flat index -> coordinates, innermost extent first: i = ((a * D1 + b) * D2 + c) * D3 + d.  32-bit arithmetic whenever
+// the index fits: a 64-bit quotient costs ~100 instructions on this ISA (it is what paced the pairwise-IoU kernel
+// before its 2-D decomposition), a 32-bit one ~25.
+__device__ __forceinline__ void split_idx(int64_t i, int D3, int D2, int D1, int& d, int& c, int& b, int& a) {
+  if (i < (1ll << 31)) {
+    const unsigned u = (unsigned)i;
+    const unsigned q = u / (unsigned)D3;
+    d = (int)(u - q * (unsigned)D3);
+    const unsigned q2 = q / (unsigned)D2;
+    c = (int)(q - q2 * (unsigned)D2);
+    const unsigned q3 = q2 / (unsigned)D1;
+    b = (int)(q2 - q3 * (unsigned)D1);
+    a = (int)q3;
+  } else {
+    d = (int)(i % D3);
+    int64_t r = i / D3;
+    c = (int)(r % D2);
+    r /= D2;
+    b = (int)(r % D1);
+    a = (int)(r / D1);
+  }
+}
+__device__ __forceinline__ void split_idx(int64_t i, int D3, int D2, int& d, int& c, int& b) {
+  if (i < (1ll << 31)) {
+    const unsigned u = (unsigned)i;
+    const unsigned q = u / (unsigned)D3;
+    d = (int)(u - q * (unsigned)D3);
+    const unsigned q2 = q / (unsigned)D2;
+    c = (int)(q - q2 * (unsigned)D2);
+    b = (int)q2;
+  } else {
+    d = (int)(i % D3);
+    const int64_t r = i / D3;
+    c = (int)(r % D2);
+    b = (int)(r / D2);
+  }
+}
+
+
 static thread_local char g_err[512] = "";
 
 void tdn_set_error(const char* fmt, ...) {
@@ -306,10 +345,8 @@ __global__ void stage_image_kernel(const float* img, int64_t s_n, int64_t s_c, i
   const int Hp = H + 6, Wp = W + 8;
   const int64_t total = (int64_t)N * Hp * Wp;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int wp = (int)(i % Wp);
-    int64_t r = i / Wp;
-    const int hp = (int)(r % Hp);
-    const int n = (int)(r / Hp);
+    int wp, hp, n;
+    split_idx(i, Wp, Hp, wp, hp, n);
     const int h = hp - 3, w = wp - 3;
     bf16x4_t v = {f32_to_elem<F16>(0.f), f32_to_elem<F16>(0.f), f32_to_elem<F16>(0.f), f32_to_elem<F16>(0.f)};
     if (h >= 0 && h < H && w >= 0 && w < W) {
@@ -340,12 +377,8 @@ __global__ void maxpool_fwd_kernel(const bf16_t* x, bf16_t* y, uint8_t* idx, int
   const int C8 = C >> 3;
   const int64_t total = (int64_t)N * Ho * Wo * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c8 = (int)(i % C8);
-    int64_t r = i / C8;
-    const int wo = (int)(r % Wo);
-    r /= Wo;
-    const int ho = (int)(r % Ho);
-    const int n = (int)(r / Ho);
+    int c8, wo, ho, n;
+    split_idx(i, C8, Wo, Ho, c8, wo, ho, n);
     float best[8];
     int bi[8];
 #pragma unroll
@@ -392,54 +425,74 @@ extern "C" int tdn_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N,
 // ReLU in front of the pool: `mask` is the pool's full-size input (gradient passes where it is > 0), or `ypool` is the
 // pool's OUTPUT — a window's value is the value of the element it selected, so "selected element > 0" can be read
 // from the 4x smaller tensor (same result bit for bit: all windows that selected one element carry its value).
+// A thread owns a 2 x 2 quad of input pixels (8 channels): its four pixels can only have been selected by the four
+// windows (k, k+1) x (m, m+1), whose idx / dy / y words are loaded ONCE (2.25 window loads per pixel before), and each
+// pixel sums its windows in ascending (ho, wo) order — PyTorch's accumulation order.
 template <bool F16>
 __global__ void maxpool_bwd_kernel(const bf16_t* dy, const uint8_t* idx, const bf16_t* mask, const bf16_t* ypool,
                                    bf16_t* dx, int N, int H, int W, int C, int Ho, int Wo) {
   const int C8 = C >> 3;
-  const int64_t total = (int64_t)N * H * W * C8;
+  const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+  const int64_t total = (int64_t)N * H2 * W2 * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c8 = (int)(i % C8);
-    int64_t r = i / C8;
-    const int w = (int)(r % W);
-    r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
-    float acc[8];
+    int c8, m, k, n;
+    split_idx(i, C8, W2, H2, c8, m, k, n);
+    // window (a, b) = (k + a, m + b): words, with code 0xff (matches no position) where the window does not exist
+    uint64_t pk[2][2];
+    bf16x8_t g[2][2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    // windows ho with ho*2-1+kh == h  ->  kh = h + 1 - 2*ho in [0,2]; ascending ho = PyTorch's accumulation order
-    const int ho_lo = max(0, (h - 1 + 1) / 2), ho_hi = min(Ho - 1, (h + 1) / 2);
-    const int wo_lo = max(0, (w - 1 + 1) / 2), wo_hi = min(Wo - 1, (w + 1) / 2);
-    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-      const int kh = h + 1 - 2 * ho;
-      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-        const int kw = w + 1 - 2 * wo;
-        const int code = kh * 3 + kw;
-        const int64_t o = ((((int64_t)n * Ho + ho) * Wo + wo) * C8 + c8) * 8;
-        const uint64_t pk = *(const uint64_t*)(idx + o);
-        const bf16x8_t g = *(const bf16x8_t*)(dy + o);
-        if (ypool) {
-          const bf16x8_t yv = *(const bf16x8_t*)(ypool + o);
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if ((int)((pk >> (8 * e)) & 0xff) == code && elem_to_f32<F16>(yv[e]) > 0.f) acc[e] += elem_to_f32<F16>(g[e]);
-        } else {
+      for (int b = 0; b < 2; ++b) {
+        const int ho = k + a, wo = m + b;
+        pk[a][b] = ~0ull;
+        g[a][b] = (bf16x8_t){};
+        if (ho < Ho && wo < Wo) {
+          const int64_t o = ((((int64_t)n * Ho + ho) * Wo + wo) * C8 + c8) * 8;
+          uint64_t p8 = *(const uint64_t*)(idx + o);
+          g[a][b] = *(const bf16x8_t*)(dy + o);
+          if (ypool) {   // ReLU in front of the pool: a window whose value is <= 0 passes nothing
+            const bf16x8_t yv = *(const bf16x8_t*)(ypool + o);
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if ((int)((pk >> (8 * e)) & 0xff) == code) acc[e] += elem_to_f32<F16>(g[e]);
+            for (int e = 0; e < 8; ++e)
+              if (!(elem_to_f32<F16>(yv[e]) > 0.f)) p8 |= 0xffull << (8 * e);
+          }
+          pk[a][b] = p8;
         }
       }
-    }
-    bf16x8_t o8;
-    if (mask) {
-      const bf16x8_t mk = *(const bf16x8_t*)(mask + i * 8);
+    // pixel (2k + r, 2m + s) is position (kh, kw) = (r + 1 - 2a, s + 1 - 2b) of window (a, b) when that is in [0, 2]
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o8[e] = f32_to_elem<F16>((elem_to_f32<F16>(mk[e]) > 0.f) ? acc[e] : 0.f);
-    } else {
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o8[e] = f32_to_elem<F16>(acc[e]);
-    }
-    *(bf16x8_t*)(dx + i * 8) = o8;
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const int h = 2 * k + r, w = 2 * m + s_;
+        if (h >= H || w >= W) continue;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int kh = r + 1 - 2 * a, kw = s_ + 1 - 2 * b;
+            if (kh < 0 || kw < 0) continue;            // compile-time after unrolling
+            const int code = kh * 3 + kw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if ((int)((pk[a][b] >> (8 * e)) & 0xff) == code) acc[e] += elem_to_f32<F16>(g[a][b][e]);
+          }
+        const int64_t px = (((int64_t)n * H + h) * W + w) * C8 + c8;
+        bf16x8_t o8;
+        if (mask) {
+          const bf16x8_t mk = *(const bf16x8_t*)(mask + px * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = f32_to_elem<F16>((elem_to_f32<F16>(mk[e]) > 0.f) ? acc[e] : 0.f);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = f32_to_elem<F16>(acc[e]);
+        }
+        *(bf16x8_t*)(dx + px * 8) = o8;
+      }
   }
 }
 
@@ -448,7 +501,7 @@ extern "C" int tdn_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, const vo
   TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "tdn_maxpool3x3s2_bwd: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int64_t total = (int64_t)N * H * W * (C / 8);
+  const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);   // one thread per 2 x 2 input quad
   TDN_LAUNCH_T(maxpool_bwd_kernel, dtype, dim3(grid_for(total, 256)), dim3(256), (hipStream_t)stream,
                      (const bf16_t*)dy, idx, (const bf16_t*)mask_src, (const bf16_t*)nullptr, (bf16_t*)dx, N, H, W, C, Ho,
                      Wo);
@@ -462,7 +515,7 @@ extern "C" int tdn_maxpool3x3s2_relu_bwd(const void* dy, const uint8_t* idx, con
   TDN_CHECK(dy && idx && y_pooled && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0,
             "tdn_maxpool3x3s2_relu_bwd: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int64_t total = (int64_t)N * H * W * (C / 8);
+  const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);   // one thread per 2 x 2 input quad
   TDN_LAUNCH_T(maxpool_bwd_kernel, dtype, dim3(grid_for(total, 256)), dim3(256), (hipStream_t)stream,
                      (const bf16_t*)dy, idx, (const bf16_t*)nullptr, (const bf16_t*)y_pooled, (bf16_t*)dx, N, H, W, C, Ho,
                      Wo);
@@ -475,12 +528,8 @@ __global__ void subsample_fwd_kernel(const bf16_t* x, bf16_t* y, int N, int H, i
   const int C8 = C >> 3;
   const int64_t total = (int64_t)N * Ho * Wo * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c8 = (int)(i % C8);
-    int64_t r = i / C8;
-    const int wo = (int)(r % Wo);
-    r /= Wo;
-    const int ho = (int)(r % Ho);
-    const int n = (int)(r / Ho);
+    int c8, wo, ho, n;
+    split_idx(i, C8, Wo, Ho, c8, wo, ho, n);
     *(bf16x8_t*)(y + i * 8) = *(const bf16x8_t*)(x + (((int64_t)n * H + 2 * ho) * W + 2 * wo) * C + c8 * 8);
   }
 }
@@ -501,12 +550,8 @@ __global__ void subsample_bwd_kernel(const bf16_t* dy, const bf16_t* dx_in, bf16
   const int C8 = C >> 3;
   const int64_t total = (int64_t)N * H * W * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c8 = (int)(i % C8);
-    int64_t r = i / C8;
-    const int w = (int)(r % W);
-    r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
+    int c8, w, h, n;
+    split_idx(i, C8, W, H, c8, w, h, n);
     float acc[8];
     if (dx_in) {
       const bf16x8_t v = *(const bf16x8_t*)(dx_in + i * 8);
@@ -625,7 +670,7 @@ template <bool F16>
 __global__ void channel_affine_kernel(const bf16_t* x, const float* scale, const float* shift, bf16_t* y,
                                       int64_t n8, int C8, int act) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C8) * 8;
+    const int c = (i < (1ll << 31) ? (int)((unsigned)i % (unsigned)C8) : (int)(i % C8)) * 8;
     const bf16x8_t v = *(const bf16x8_t*)(x + i * 8);
     bf16x8_t o;
 #pragma unroll
@@ -922,9 +967,8 @@ __global__ void collate_staged_kernel(const CollateArgs a, bf16_t* xp) {
   const int Hp = a.Hb + 6, Wp = a.Wb + 8;
   const int64_t total = (int64_t)a.n * Hp * Wp;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int wp = (int)(i % Wp);
-    const int64_t r = i / Wp;
-    const int hp = (int)(r % Hp), n = (int)(r / Hp);
+    int wp, hp, n;
+    split_idx(i, Wp, Hp, wp, hp, n);
     const int y = hp - 3, x = wp - 3;
     float v[3] = {0.f, 0.f, 0.f};
     if (y >= 0 && y < a.Hb && x >= 0 && x < a.Wb) collate_pixel<SRC_F32>(a, n, y, x, v);
