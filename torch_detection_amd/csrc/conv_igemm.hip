@@ -409,6 +409,35 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
     }
   };
   if constexpr (EARLY_EPI) load_affine();   // older than every LDS-DMA: the counted vmcnt waits retire them first
+  // Small tiles also fetch the epilogue's per-pixel operands here — the residual addend (same-size mode) and the ReLU
+  // mask source of the lane's own outputs — so their latency runs beside the prologue's first-data latency instead
+  // of behind the K loop (they are older than every LDS-DMA too).  Same values, same arithmetic order.
+  // Only where the 16 extra registers cost no occupancy: the 64x64 4-wave tile (80 -> 96); the 128x128 8-wave tile would
+  // cross 128 registers (two workgroups per CU -> one).
+  constexpr bool PRE_EPI = EARLY_EPI && FN * FM <= 4 && WIDE && OWN_BY_J && KG == 1 && TAG != 2;
+  bf16x8_t pre_add[PRE_EPI ? FM : 1][PRE_EPI ? FN / 2 : 1], pre_msk[PRE_EPI ? FM : 1][PRE_EPI ? FN / 2 : 1];
+  const bool pre_have_add = PRE_EPI && p.addend_mode == TDN_ADD_SAME;
+  const bool pre_have_msk = PRE_EPI && p.mask != nullptr;
+  if constexpr (PRE_EPI) {
+    if (pre_have_add || pre_have_msk) {
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int m = m0 + wm * WTM + j * 16 + fr;
+        if (m < cM) {
+          const int img = fast_div(m, mul_hw, shr_hw);
+          const int rem = m - img * HaWa;
+          const int a = fast_div(rem, mul_w, shr_w);
+          const int b = rem - a * cWa;
+          const int64_t opix = ((int64_t)img * p.Hout + (a * p.so + c.oh0)) * p.Wout + (b * p.so + c.ow0);
+#pragma unroll
+          for (int h = 0; h < FN / 2; ++h) {
+            if (pre_have_add) pre_add[j][h] = *(const bf16x8_t*)(p.addend + opix * p.Cout + ch_base + h * 8);
+            if (pre_have_msk) pre_msk[j][h] = *(const bf16x8_t*)(p.mask + opix * p.Cout + ch_base + h * 8);
+          }
+        }
+      }
+    }
+  }
 
   if (Tg > 0) {
     TDN_TRACE(1);
@@ -696,7 +725,19 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
           for (int e = 0; e < 4; ++e) { v[2 * h][e] += acc8[e]; v[2 * h + 1][e] += acc8[4 + e]; }
         }
       } else if (p.addend_mode != TDN_ADD_NONE) {
-        add_row(p.addend + apix * p.Cout + ch_base);
+        if (pre_have_add) {
+#pragma unroll
+          for (int h = 0; h < FN / 2; ++h) {
+            const bf16x8_t r = pre_add[PRE_EPI ? j : 0][PRE_EPI ? h : 0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * h][e] += elem_to_f32<F16>(r[e]);
+              v[2 * h + 1][e] += elem_to_f32<F16>(r[4 + e]);
+            }
+          }
+        } else {
+          add_row(p.addend + apix * p.Cout + ch_base);
+        }
       }
       if (p.relu) {
 #pragma unroll
@@ -713,7 +754,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64) void conv_gemm_kernel(const Gemm
       if (p.mask) {
 #pragma unroll
         for (int h = 0; h < FN / 2; ++h) {
-          const bf16x8_t mk = *(const bf16x8_t*)(p.mask + opix * p.Cout + ch_base + h * 8);
+          const bf16x8_t mk = pre_have_msk ? pre_msk[PRE_EPI ? j : 0][PRE_EPI ? h : 0]
+                                           : *(const bf16x8_t*)(p.mask + opix * p.Cout + ch_base + h * 8);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v[2 * h][e] = (elem_to_f32<F16>(mk[e]) > 0.f) ? v[2 * h][e] : 0.f;
