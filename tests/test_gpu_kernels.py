@@ -58,8 +58,9 @@ CONV_CASES = [
 
 # GEMM tile configurations forced through TDN_GEMM_CFG (ids of kCfgs in csrc/conv_igemm.hip): the production set —
 # 0: 64x64, 1: 64x128 (pipelined fragments), 3: 192x256 (8 waves), 25: 64x64 with two split-K wave groups,
-# 46: 128x128 (8 waves) — on top of whatever the library picks by itself (None)
-GEMM_CFGS = {None: 64, 0: 64, 1: 128, 3: 256, 25: 64, 46: 128}
+# 46: 128x128 (8 waves), 50: 64x64 with 128-deep K-steps (falls back to the library's choice where Cin % 128 != 0) —
+# on top of whatever the library picks by itself (None)
+GEMM_CFGS = {None: 64, 0: 64, 1: 128, 3: 256, 25: 64, 46: 128, 50: 64}
 
 
 @pytest.mark.parametrize("tile", list(GEMM_CFGS))
@@ -93,7 +94,7 @@ def test_conv_fwd(ops, case, tile):
         os.environ.pop("TDN_GEMM_CFG", None)
 
 
-@pytest.mark.parametrize("tile", [None, 3, 25, 46])
+@pytest.mark.parametrize("tile", [None, 3, 25, 46, 50])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_dgrad(ops, case, tile, monkeypatch):
     N, H, W, Cin, Cout, k, s = case

@@ -996,10 +996,24 @@ static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0, int ktap 
 #ifdef TDN_TRACE_BUILD
     const bool built = true;
 #else
-    const bool built = id == 0 || id == 1 || id == 2 || id == 3 || id == 25 || id == 46;   // production tiles
+    const bool built = id == 0 || id == 1 || id == 2 || id == 3 || id == 25 || id == 46 || id == 50;   // production tiles
 #endif
     if (id >= 0 && id < kNumCfgs && built && ngemm % kCfgs[id].bn == 0 && ktap % kCfgs[id].bk == 0) return id;
   }
+#ifdef TDN_TRACE_BUILD
+  // experiments (libtdn_trace.so): TDN_CFG_RULE="M:N:K:cfg,M:N:K:cfg,..." picks a configuration for exactly that GEMM
+  if (const char* rule = getenv("TDN_CFG_RULE")) {
+    const char* q = rule;
+    while (*q) {
+      int m_ = 0, n_ = 0, k_ = 0, id = -1;
+      if (sscanf(q, "%d:%d:%d:%d", &m_, &n_, &k_, &id) == 4 && m_ == maxM && n_ == ngemm && k_ == kgemm && id >= 0 &&
+          id < kNumCfgs && ngemm % kCfgs[id].bn == 0 && ktap % kCfgs[id].bk == 0)
+        return id;
+      while (*q && *q != ',') ++q;
+      if (*q == ',') ++q;
+    }
+  }
+#endif
   // Measured on MI355X over the R50-FPN shapes (scripts/conv_bench.py; profiles/convbench_*.log): several small
   // co-resident workgroups per CU (64-pixel tiles, 2-deep ring, 32-48 KB LDS) beat one large deeply pipelined
   // workgroup on almost every shape; only the very large-M 3x3 convs prefer the 256x128 8-wave tile.
@@ -1016,6 +1030,14 @@ static int choose_cfg(int maxM, int ngemm, int kgemm, int grouped = 0, int ktap 
   const int kg_tiles = getenv("TDN_KG_TILES") ? atoi(getenv("TDN_KG_TILES")) : 512;
   const int kg_kmin = getenv("TDN_KG_KMIN") ? atoi(getenv("TDN_KG_KMIN")) : 2048;
   if ((long)ceil_div(maxM, 64) * (ngemm / 64) <= kg_tiles && kgemm >= kg_kmin) return 25;
+  // at most about one 64x64 tile per CU and a K loop of 16-31 steps (layer3's 1024 -> 256 convs and the dgrad of its
+  // 256 -> 1024 ones, per image: 264 tiles): 128-deep K-steps halve the barriers of a workgroup that has its CU to
+  // itself.  Whole-step A/B on one box, three interleaved pairs: +0.6-0.9 %; the same tile on the neighbouring shapes
+  // (528 tiles, or K = 512, or K = 2048 where the K groups above already apply) is neutral to -0.7 %.
+  const int bk128_tiles = getenv("TDN_BK128_TILES") ? atoi(getenv("TDN_BK128_TILES")) : 300;
+  // 1x1 convs only: with several taps a 128-deep chunk changes the (chunk outer, taps inner) summation order
+  if (kgemm == ktap && (long)ceil_div(maxM, 64) * (ngemm / 64) <= bk128_tiles && kgemm >= 1024 && ktap % 128 == 0)
+    return 50;
   if (ngemm % 128 == 0) {
     // A K-step costs ~1300-1500 cycles of load latency whatever the tile (scripts/trace_gemm.py), so the 128x128
     // tile does 2-4x the work per step of the 64-wide ones; with 8 waves (wave tile 64x32) two of them fit a CU.
@@ -1107,6 +1129,7 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
       case 3: return launch_gemm<192, 256, 64, 2, 4, 2, 6, 0, 1, true>(p, maxM, stream);
       case 25: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 2, true>(p, maxM, stream);
       case 46: return launch_gemm<128, 128, 64, 2, 4, 2, 6, 0, 1, true>(p, maxM, stream);
+      case 50: return launch_gemm<64, 64, 128, 2, 2, 2, 0, 0, 1, true>(p, maxM, stream);
       default: TDN_CHECK(false, "GEMM config %d (TDN_GEMM_CFG) has no TDN_F16 build", id); return -1;
     }
   }
@@ -1122,6 +1145,7 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
       return launch_gemm<192, 256, 64, 2, 4, 2, 6>(p, maxM, stream);
     case 25: return launch_gemm<64, 64, 64, 2, 2, 2, 0, 0, 2>(p, maxM, stream);
     case 46: return launch_gemm<128, 128, 64, 2, 4, 2, 6, 0>(p, maxM, stream);
+    case 50: return launch_gemm<64, 64, 128, 2, 2, 2, 0, 0>(p, maxM, stream);
 #ifdef TDN_TRACE_BUILD   // alternates, ablations and cycle-stamp builds: libtdn_trace.so only (make TRACE=1)
     case 4: return launch_gemm<64, 128, 64, 2, 2, 2, 0>(p, maxM, stream);
     case 5: return launch_gemm<64, 128, 64, 2, 2, 3, 0>(p, maxM, stream);
@@ -1167,7 +1191,6 @@ static int dispatch_gemm(GemmParams& p, int maxM, hipStream_t stream, int dtype)
     case 47: return launch_gemm<64, 64, 64, 2, 2, 2, 10, 2>(p, maxM, stream);
     case 48: return launch_gemm<64, 64, 64, 2, 2, 4, 10, 2>(p, maxM, stream);
     case 49: return launch_gemm<192, 256, 64, 2, 4, 2, 10, 2>(p, maxM, stream);
-    case 50: return launch_gemm<64, 64, 128, 2, 2, 2, 0, 0>(p, maxM, stream);
     case 51: return launch_gemm<64, 128, 128, 2, 2, 2, 0, 0>(p, maxM, stream);
     case 52: return launch_gemm<128, 128, 128, 2, 4, 2, 0, 0>(p, maxM, stream);
     case 53: return launch_gemm<64, 64, 128, 2, 2, 2, 0, 2>(p, maxM, stream);
