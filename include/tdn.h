@@ -225,6 +225,13 @@ int tdn_stage_image(const float* img, int64_t s_n, int64_t s_c, int64_t s_h, int
 int tdn_stem_conv_fwd(const void* xp, const void* w_stem, void* y, int N, int H, int W, int Cout,
                       const tdn_epilogue* ep, int dtype, void* stream);
 
+/* The stem in one launch: conv7x7/s2 (tdn_stem_conv_fwd) + eval-mode BN (scale, shift: tdn_bn_fold) + ReLU +
+ * MaxPool2d(3, 2, 1) (tdn_maxpool3x3s2_fwd) — resnet.py:214-218, 254-258.  y[N][Ho][Wo][64] and idx (window
+ * position of the first maximum) are bit-identical to the two separate calls; the stem's full-size activation is
+ * never written (backward: tdn_maxpool3x3s2_relu_bwd reads the ReLU mask from y).  Cout must be 64; H, W even. */
+int tdn_stem_pool_fwd(const void* xp, const void* w_stem, const float* scale, const float* shift,
+                      void* y, uint8_t* idx, int N, int H, int W, int Cout, int dtype, void* stream);
+
 int64_t tdn_stem_conv_wgrad_workspace(int N, int H, int W, int Cout);
 
 /* dw fp32 [Cout][3][7][7] contiguous (+ BN grads as in tdn_conv2d_wgrad). */

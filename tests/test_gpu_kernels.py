@@ -191,6 +191,27 @@ def test_conv_wgrad(ops, case, bn, monkeypatch):
     assert rel_l2(db2.cpu(), 2 * beta.grad) <= TOL
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1, 30, 44), (3, 64, 96), (2, 128, 160), (1, 226, 318)])
+def test_stem_pool_fused_equals_two_launches(ops, shape, dtype):
+    """tdn_stem_pool_fwd (conv7x7/s2 + BN + ReLU + max pool in one launch) against tdn_stem_conv_fwd followed by
+    tdn_maxpool3x3s2_fwd: pooled values and window indices bit for bit (odd conv grids, patches that overhang the
+    image, ties at zero after the ReLU)."""
+    N, H, W = shape
+    img = (det_tensor((N, 3, H, W), 241, -2, 2) * 4).round() / 4          # coarse values: many exact ties
+    w = det_tensor((64, 3, 7, 7), 242, -0.2, 0.2)
+    scale = det_tensor((64,), 243, 0.5, 1.5, bf16=False).cuda()
+    shift = det_tensor((64,), 244, -1.5, 0.5, bf16=False).cuda()         # mostly negative: ReLU zeros are common
+    xp = ops.stage_image(img.cuda(), dtype)
+    ws = ops.pack_stem_weight(w.cuda(), dtype)
+    s = ops.stem_conv_fwd(xp, ws, (H, W), scale, shift, True)
+    y0, i0 = ops.maxpool3x3s2_fwd(s)
+    y1, i1 = ops.stem_pool_fwd(xp, ws, (H, W), scale, shift)
+    assert torch.equal(y0, y1)
+    assert torch.equal(i0, i1)
+    assert float((y0 == 0).float().mean()) > 0.05     # the tie case is really exercised
+
+
 @pytest.mark.parametrize("shape", [(1, 32, 48), (2, 64, 96)])
 def test_stem(ops, shape):
     N, H, W = shape

@@ -106,6 +106,7 @@ SIGNATURES = {
     "tdn_stage_image": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_int,
                                 c_void_p]),
     "tdn_stem_conv_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [_EP, c_int, c_void_p]),
+    "tdn_stem_pool_fwd": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "tdn_stem_conv_wgrad_workspace": (c_i64, [c_int] * 4),
     "tdn_stem_conv_wgrad": (c_int, [c_void_p] * 9 + [c_float] + [c_int] * 4 + [c_void_p, c_i64, c_int, c_void_p]),
     "tdn_maxpool3x3s2_fwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),

@@ -1029,6 +1029,20 @@ def _stem_fwd(u, xp, hw):
     return s
 
 
+def _stem_pool_fwd(u, xp, hw):
+    """Stem + max pool (resnet.py:254-258): (stem activation or None, pooled output, window indices).  The plain stem —
+    64 channels, eval-mode BN folded into the conv — runs as ONE launch that never writes its full-size activation
+    (ops.stem_pool_fwd, bit-identical to the two launches); TDN_STEM_FUSED=0, a parity test's DEBUG_CAPTURE (it looks
+    at the stem activation) and every other stem variant take the two launches."""
+    if (not (u.gn or u.bnt) and u.Cout == 64 and u.scale is not None and u.shift is not None and
+            DEBUG_CAPTURE is None and os.environ.get('TDN_STEM_FUSED', '1') != '0'):
+        y, idx = ops.stem_pool_fwd(xp, u.w_fwd, hw, u.scale, u.shift)
+        return None, y, idx
+    s = _stem_fwd(u, xp, hw)
+    y, idx = ops.maxpool3x3s2_fwd(s)
+    return s, y, idx
+
+
 class SeqNetFunction(torch.autograd.Function):
     """ResNet.forward (resnet.py:253-268) — or a single residual block — as one autograd node."""
 
@@ -1046,8 +1060,7 @@ class SeqNetFunction(torch.autograd.Function):
             if x.dtype != net.dtype:
                 raise RuntimeError('staged images are %s but the net computes in %s' % (x.dtype, net.dtype))
             xp, (H, W) = x.xp, x.hw
-            s = _stem_fwd(net.stem, xp, (H, W))
-            cur, idx = ops.maxpool3x3s2_fwd(s)
+            s, cur, idx = _stem_pool_fwd(net.stem, xp, (H, W))
             st.update(xp=xp, y=cur, idx=idx, img_hw=(H, W))   # the stem's own output is not kept: see maxpool3x3s2_bwd
         elif net.stem is not None:
             if x.dim() != 4 or x.shape[1] != 3:
@@ -1055,8 +1068,7 @@ class SeqNetFunction(torch.autograd.Function):
             img = x if x.dtype == torch.float32 else x.float()
             H, W = img.shape[2], img.shape[3]
             xp = ops.stage_image(img, net.dtype)
-            s = _stem_fwd(net.stem, xp, (H, W))
-            cur, idx = ops.maxpool3x3s2_fwd(s)
+            s, cur, idx = _stem_pool_fwd(net.stem, xp, (H, W))
             st.update(xp=xp, y=cur, idx=idx, img_hw=(H, W))   # the stem's own output is not kept: see maxpool3x3s2_bwd
         else:
             cur = ops.to_nhwc_bf16(x, net.dtype)

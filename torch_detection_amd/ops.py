@@ -393,6 +393,29 @@ def stem_conv_fwd(xp, w_stem, hw, scale=None, shift=None, relu=True, out_f32=Fal
     return y
 
 
+def stem_pool_fwd(xp, w_stem, hw, scale, shift):
+    """conv7x7/s2 + folded BN + ReLU + MaxPool2d(3, 2, 1) in one launch (``tdn_stem_pool_fwd``): returns the pooled
+    output and the window indices, bit-identical to ``maxpool3x3s2_fwd(stem_conv_fwd(...))``; 64 output channels."""
+    H, W = hw
+    N = xp.shape[0]
+    Cout = w_stem.shape[0]
+    if tuple(xp.shape) != (N, H + 6, W + 8, 4) or xp.dtype not in _CODES or not xp.is_contiguous():
+        raise ValueError("xp must be the staged image (N,H+6,W+8,4) in bf16/fp16")
+    if tuple(w_stem.shape) != (Cout, 7, 8, 4) or w_stem.dtype != xp.dtype or Cout != 64:
+        raise ValueError("w_stem must be %s [64,7,8,4]" % (xp.dtype,))
+    if H % 2 or W % 2:
+        raise RuntimeError("stem conv needs even H and W (got %dx%d)" % (H, W))
+    for t, nm in ((scale, "scale"), (shift, "shift")):
+        if t is None or t.dtype != torch.float32 or t.numel() != Cout or not t.is_contiguous() or t.device != xp.device:
+            raise ValueError("stem_pool_fwd: %s must be a contiguous float32 [%d] tensor on the image's device" % (nm, Cout))
+    Ho, Wo = conv_out_size(H // 2, 3, 2, 1), conv_out_size(W // 2, 3, 2, 1)
+    y = torch.empty(N, Ho, Wo, Cout, dtype=xp.dtype, device=xp.device)
+    idx = torch.empty(N, Ho, Wo, Cout, dtype=torch.uint8, device=xp.device)
+    _lib.check(_lib.load().tdn_stem_pool_fwd(_ptr(xp), _ptr(w_stem), _ptr(scale), _ptr(shift), _ptr(y), _ptr(idx), N, H,
+                                             W, Cout, dtype_code(xp.dtype), _lib.stream_ptr()), "tdn_stem_pool_fwd")
+    return y, idx
+
+
 def stem_conv_wgrad_item(xp, g, w_stem, hw, scale=None, mean=None, invstd=None, dw=None, dgamma=None, dbeta=None,
                          beta=0.0, want_dbeta=True):
     H, W = hw
