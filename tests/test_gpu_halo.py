@@ -120,12 +120,18 @@ def test_halo_conv3x3_fwd_dgrad(ops, case, cfg):
 def test_halo_default_shapes_take_the_kernel(ops):
     """What the library routes to the halo kernel by itself (the BASELINE step's 3x3 stride-1 layers with >= 128
     output channels, per image and per batch) — and what it leaves to the generic kernel."""
-    taken = [(2, 200, 336, 256, 256), (1, 100, 168, 128, 128), (2, 50, 84, 256, 256), (1, 50, 84, 256, 256),
-             (1, 25, 42, 512, 512)]
+    taken = [(1, 100, 168, 128, 128), (2, 50, 84, 256, 256), (1, 50, 84, 256, 256), (1, 25, 42, 512, 512)]
     for N, H, W, Cin, Cout in taken:
         assert uses_halo(ops, 0, N, H, W, Cin, Cout, 3, 1, 1), (N, H, W, Cin, Cout)
         assert uses_halo(ops, 1, N, H, W, Cin, Cout, 3, 1, 1), (N, H, W, Cin, Cout)
     assert not uses_halo(ops, 0, 2, 200, 336, 64, 64, 3, 1, 1)       # layer1: 64 output channels
+    # the largest layer (fpn_convs.0): faster alone with the halo tile, slower in the step -> generic unless asked for
+    assert not uses_halo(ops, 0, 2, 200, 336, 256, 256, 3, 1, 1)
+    os.environ["TDN_HALO_BIG"] = "1"
+    try:
+        assert uses_halo(ops, 0, 2, 200, 336, 256, 256, 3, 1, 1) and uses_halo(ops, 1, 2, 200, 336, 256, 256, 3, 1, 1)
+    finally:
+        os.environ.pop("TDN_HALO_BIG")
     assert not uses_halo(ops, 0, 2, 100, 168, 128, 128, 3, 2, 1)     # stride 2
     assert not uses_halo(ops, 0, 2, 50, 84, 256, 1024, 1, 1, 0)      # 1x1 layers stay with the generic kernel
     assert not uses_halo(ops, 0, 2, 25, 42, 256, 256, 3, 1, 1)       # fpn_convs.3: too few pixels at 256 channels

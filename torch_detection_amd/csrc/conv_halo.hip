@@ -658,7 +658,11 @@ static bool halo_make_plan(const HaloShape& s, HaloPlan* pl) {
   // many small co-resident workgroups hide better (measured 1.3-2x slower here).
   int cfg = -1;
   if (s.k == 3 && s.Cout % 128 == 0) {
-    if (M >= 100000) cfg = 1;                       // fpn_convs.0 and its dgrad
+    // The largest layer (fpn_convs.0 and its dgrad, M = 134,400): the 256 x 128 tile is 5 % faster than the generic
+    // 192 x 256 tile alone (167 vs 175 us) but the whole step is 0.7-0.9 % SLOWER with it (three interleaved pairs on
+    // one box: 469.8 vs 473.1 img/s) — it runs beside the FPN's nine-tap weight-gradient group and co-runs worse.
+    // TDN_HALO_BIG=1 selects it.
+    if (M >= 100000) cfg = halo_env_int("TDN_HALO_BIG", 0) ? 1 : -1;
     else if (M >= 6000 && M < 30000) cfg = 11;      // layer2 per image, layer3 / P4 per batch: 128 x 128, 4 + 4 waves
     else if (M < 6000 && s.Cin >= 256 && (s.Cin >= 512 || M >= 3000))
       cfg = 10;   // layer3 / layer4 per image: 128 x 64, 4 + 4 waves (P5's 256-channel conv, M = 2,100: generic 13 vs 16 us)
