@@ -964,9 +964,10 @@ static int plan_group(const tdn_wgrad_item* items, int n, std::vector<ItemPlan>&
   plans.resize(n);
   const int t9_mode = env_int("TDN_WGRAD9", 1);   // 0: never use the nine-tap kernel
   const int shape_env = env_int("TDN_WGRAD_SHAPE", -1);   // force kTapShapes[id] where it divides the member
-  const int s256 = env_int("TDN_WGRAD_S256", 5), s128 = env_int("TDN_WGRAD_S128", 4), s64 = env_int("TDN_WGRAD_S64", 2);
+  const int s256 = env_int("TDN_WGRAD_S256", 8), s128 = env_int("TDN_WGRAD_S128", 4), s64 = env_int("TDN_WGRAD_S64", 2);
+  const int s256f = env_int("TDN_WGRAD_S256F", 5);   // 256-channel members whose Cin does not divide the s256 tile
   const int uniform = env_int("TDN_WGRAD_UNIFORM", 0);   // 1: one tile shape per group (fewest launches)
-  const int tmin_tap = env_int("TDN_WGRAD_TMIN", 24), tmin_t9 = env_int("TDN_WGRAD9_TMIN", 16);
+  const int tmin_tap = env_int("TDN_WGRAD_TMIN", 24), tmin_t9 = env_int("TDN_WGRAD9_TMIN", 32);
   const int direct_ok = env_int("TDN_WGRAD_DIRECT", 1);
   int min_bmw = 256;
   for (int i = 0; i < n; ++i) {
@@ -991,9 +992,12 @@ static int plan_group(const tdn_wgrad_item* items, int n, std::vector<ItemPlan>&
       int bmw = g.Cout % 256 == 0 ? 256 : (g.Cout % 128 == 0 ? 128 : 64);
       if (uniform && bmw > min_bmw) bmw = min_bmw;
       int shape = g.Ktap == 32 ? 0 : ((g.grouped || bmw == 64) ? s64 : (bmw == 128 ? s128 : s256));
-      if (shape < 0 || shape >= kNumTapShapes || g.Cout % kTapShapes[shape].bmw || g.Ktap % kTapShapes[shape].bnw ||
-          (g.grouped && (kTapShapes[shape].bmw != 64 || kTapShapes[shape].bnw != 64)))
-        shape = g.Ktap == 32 ? 0 : (g.Ktap % 64 == 0 ? 2 : 0);
+      auto fits = [&](int sh) {
+        return sh >= 0 && sh < kNumTapShapes && g.Cout % kTapShapes[sh].bmw == 0 && g.Ktap % kTapShapes[sh].bnw == 0 &&
+               !(g.grouped && (kTapShapes[sh].bmw != 64 || kTapShapes[sh].bnw != 64));
+      };
+      if (!fits(shape) && bmw == 256 && !g.grouped && fits(s256f)) shape = s256f;   // e.g. Cin = 64 under a 128-wide ci tile
+      if (!fits(shape)) shape = g.Ktap == 32 ? 0 : (g.Ktap % 64 == 0 ? 2 : 0);
       if (shape_env >= 0 && shape_env < kNumTapShapes && !g.grouped && g.Cout % kTapShapes[shape_env].bmw == 0 &&
           g.Ktap % kTapShapes[shape_env].bnw == 0)
         shape = shape_env;
