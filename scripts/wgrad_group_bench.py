@@ -33,7 +33,8 @@ def stage_shapes(depth=50):
 
 
 def t9_eligible(cin, cout, k, s, W):
-    return k == 3 and s == 1 and cout % 128 == 0 and cin % 64 == 0 and W >= 8
+    return k == 3 and s == 1 and cout % 64 == 0 and cin % 64 == 0 and W >= 8 and \
+        (cout % 128 == 0 or os.environ.get('TDN_WGRAD9_64', '1') != '0')
 
 
 def fake_items(shapes, B, bn=True):

@@ -388,12 +388,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_group_kernel(const Wg
 // 43 KB of LDS-DMA per K-step (two stages: 86 KB of LDS, one workgroup per CU) feed 9 x 128 x 64 x 64 MACs: 219 flop/B
 // against 51 for the 256x64 single-tap tile.
 // Needs W >= 8 (at most one line end per 8 consecutive pixels).  Slab layout: slab[split][co][tap*Cin + ci].
-template <bool F16>
-__global__ __launch_bounds__(512) void conv_wgrad9_group_kernel(const WgGroup grp) {
+// WMR = wave rows: 4 -> 128 output channels per workgroup (8 waves), 2 -> 64 (4 waves: the 64-channel 3x3 convs of
+// layer1, whose tap-per-tile launches were most of the step's last stretch).
+template <bool F16, int WMR = 4>
+__global__ __launch_bounds__(WMR * 128) void conv_wgrad9_group_kernel(const WgGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BKW = 64, BMW = 128, BNW = 64;
-  constexpr int RBG = BMW * 2, RBX = BNW * 2;                 // 256 / 128 bytes per row
-  constexpr int G_TILE = BKW * RBG;                           // 16 KB
+  constexpr int BKW = 64, BMW = 32 * WMR, BNW = 64;
+  constexpr int NWV = WMR * 2;                                // waves
+  constexpr int RBG = BMW * 2, RBX = BNW * 2;                 // 256 (128) / 128 bytes per row
+  constexpr int CPRG = RBG / 16, RPIG = 64 / CPRG;            // 16-byte chunks per g row, g rows per wave piece
+  constexpr int XIT = 64 / (NWV * 8);                         // passes over the 64 window rows (+ one for rows 64..71)
+  static_assert(RPIG * NWV == 32 && XIT >= 1, "loader layout");
+  constexpr int G_TILE = BKW * RBG;                           // 16 (8) KB
   constexpr int XROWS = 72;                                   // 66 used
   constexpr int X_TILE = XROWS * RBX;                         // 9 KB per dh window
   constexpr int STAGE = G_TILE + 3 * X_TILE;                  // 43 KB
@@ -424,16 +430,16 @@ __global__ __launch_bounds__(512) void conv_wgrad9_group_kernel(const WgGroup gr
   const bf16_t* zero = (const bf16_t*)g_zero_page;
 
   // ---- loader state: 2 g rows per lane; per dh window 1 x row per lane (+ rows 64..71 from wave 0) ----
-  const int g_lrow = lane >> 4, g_pc = lane & 15;             // 4 rows x 16 chunks per piece
+  const int g_lrow = lane / CPRG, g_pc = lane % CPRG;         // RPIG rows x CPRG chunks per piece
   const int x_lrow = lane >> 3, x_pc = lane & 7;              // 8 rows x 8 chunks per piece
-  const int g_row0 = wave * 4 + g_lrow;                       // + it*32
-  const int x_row0 = wave * 8 + x_lrow;                       // + it*64
+  const int g_row0 = wave * RPIG + g_lrow;                    // + it*32
+  const int x_row0 = wave * 8 + x_lrow;                       // + it*(NWV*8); the last pass (rows 64..71): wave 0 only
   const int g_src_el = ((((g_pc >> 1) ^ tr_swz<RBG>(g_row0)) << 1) | (g_pc & 1)) * 8;
   const int x_src_el = ((((x_pc >> 1) ^ tr_swz<RBX>(x_row0)) << 1) | (x_pc & 1)) * 8;
-  int xh[2], xw[2];                                           // (row, column) of pixel q0 = m0 + i - 1 of the x rows
+  int xh[XIT + 1], xw[XIT + 1];                               // (row, column) of pixel q0 = m0 + i - 1 of the x rows
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int q = m_begin + it * 64 + x_row0 - 1;             // may be -1
+  for (int it = 0; it <= XIT; ++it) {
+    const int q = m_begin + it * (NWV * 8) + x_row0 - 1;      // may be -1
     const int qq = q < 0 ? q + W * H : q;                     // keep the decode non-negative; q = -1 is masked below
     xw[it] = qq % W;
     xh[it] = (qq / W) % H;
@@ -446,17 +452,17 @@ __global__ __launch_bounds__(512) void conv_wgrad9_group_kernel(const WgGroup gr
     for (int it = 0; it < 2; ++it) {
       const int m = mt + it * 32 + g_row0;
       const bf16_t* src = (m < m_end) ? gg + ((int64_t)m * Cout + co0 + g_src_el) : zero + (g_src_el & 127);
-      glds16_async(src, sG + (it * 32 + wave * 4) * RBG);
+      glds16_async(src, sG + (it * 32 + wave * RPIG) * RBG);
     }
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int i = it * 64 + x_row0;                 // window row
-      if (it == 1 && wave != 0) break;                // rows 64..71: one piece, wave 0 only (wave-uniform)
+    for (int it = 0; it <= XIT; ++it) {
+      const int i = it * (NWV * 8) + x_row0;          // window row
+      if (it == XIT && wave != 0) break;              // rows 64..71: one piece, wave 0 only (wave-uniform)
       const int q0 = mt + i - 1;
       const bool in = (i < 66) && q0 >= 0 && q0 < pM;
       const bf16_t* src = gx + ((int64_t)q0 * Cpix + ci0 + x_src_el);
       const bf16_t* z = zero + (x_src_el & 127);
-      char* dst = sX + (it * 64 + wave * 8) * RBX;
+      char* dst = sX + (it * (NWV * 8) + wave * 8) * RBX;
       glds16_async((in && xh[it] != 0) ? src - (int64_t)W * Cpix : z, dst);               // dh = -1: row above
       glds16_async(in ? src : z, dst + X_TILE);                                           // dh =  0
       glds16_async((in && xh[it] != H - 1) ? src + (int64_t)W * Cpix : z, dst + 2 * X_TILE);  // dh = +1: row below
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9_group_kernel(const WgGroup gr
       if (grp4 == 0) red[wn * BMW + wm * WTM + i * 16 + fr] = d;
     }
     __syncthreads();
-    for (int c = tid; c < BMW; c += 512) {
+    for (int c = tid; c < BMW; c += NWV * 64) {
       float s = red[c];
 #pragma unroll
       for (int w = 1; w < WN; ++w) s += red[w * BMW + c];
@@ -841,7 +847,7 @@ struct ItemPlan {
   int Hin, Win, Cpix, Ktap, Ho, Wo, Cout, sa, M, ntaps, Ktot, tapgen, grouped, map_mode;
   bool t9_ok, bn;
   // decomposition
-  int variant;   // 1: nine-tap kernel, 0: tap-per-tile kernel with shape kTapShapes[shape]
+  int variant;   // nine-tap kernel: 1 = 128-channel tile, 2 = 64-channel tile; 0: tap-per-tile kernel with shape kTapShapes[shape]
   int shape;
   int tiles_co, tiles_k, splitk, mchunk, direct, blocks, ndot;
   int step_clk, tmin, slots;   // cost model: cycles per K-step, fewest K-steps per split, workgroup slots of the chip
@@ -878,7 +884,7 @@ static int item_geometry(const tdn_wgrad_item& it, ItemPlan& g) {
                 "grouped conv: need C %% 64 == 0 and channels per group dividing 64 (C=%d, groups=%d)", C, groups);
       g.grouped = 1; g.Ktap = 64; g.map_mode = 4 * (C / groups);
     } else {
-      g.t9_ok = (k == 3 && stride == 1 && pad == 1 && it.W >= 8 && it.Cout % 128 == 0 && it.Cin % 64 == 0);
+      g.t9_ok = (k == 3 && stride == 1 && pad == 1 && it.W >= 8 && it.Cout % 64 == 0 && it.Cin % 64 == 0);
     }
   }
   TDN_CHECK(g.Ho > 0 && g.Wo > 0, "wgrad item: empty output");
@@ -893,13 +899,13 @@ static int item_geometry(const tdn_wgrad_item& it, ItemPlan& g) {
 static std::mutex g_plan_mutex;
 static std::unordered_map<uint64_t, double> g_plan_cache;   // immutable facts about shapes: split duration per group
 
-static inline int launch_key(const ItemPlan& g) { return g.variant ? -1 : g.shape; }
+static inline int launch_key(const ItemPlan& g) { return g.variant ? -g.variant : g.shape; }
 
 // members of one launch: all nine-tap members / all members of one tile shape, at most WG_MAXI at a time; launch
 // order: nine-tap members first (longest workgroups); members keep their order inside a launch
 static void launch_lists(const std::vector<ItemPlan>& plans, std::vector<std::vector<int>>& lists) {
   const int n = (int)plans.size();
-  for (int key = -1; key < kNumTapShapes; ++key) {
+  for (int key = -2; key < kNumTapShapes; ++key) {
     std::vector<int> cur;
     for (int i = 0; i < n; ++i) {
       if (launch_key(plans[i]) != key) continue;
@@ -938,7 +944,7 @@ static double model_group(const std::vector<ItemPlan>& plans, const std::vector<
     double end = 0.0;
     for (int i : L) {
       const ItemPlan& g = plans[i];
-      const int tile_floats = g.variant ? 9 * 128 * 64 : kTapShapes[g.shape].bmw * kTapShapes[g.shape].bnw;
+      const int tile_floats = g.variant ? 9 * (g.variant == 2 ? 64 : 128) * 64 : kTapShapes[g.shape].bmw * kTapShapes[g.shape].bnw;
       const double c = (double)ceil_div(g.mchunk, 64) * g.step_clk + tile_floats * 4.0 / 20.0 + 3000.0;
       const int live = g.splitk * g.tiles_co * g.tiles_k;
       for (int b = 0; b < live; ++b) {
@@ -963,6 +969,7 @@ static int plan_group(const tdn_wgrad_item* items, int n, std::vector<ItemPlan>&
   TDN_CHECK(items != nullptr && n > 0, "wgrad group: no items");
   plans.resize(n);
   const int t9_mode = env_int("TDN_WGRAD9", 1);   // 0: never use the nine-tap kernel
+  const int t9_64 = env_int("TDN_WGRAD9_64", 1);
   const int shape_env = env_int("TDN_WGRAD_SHAPE", -1);   // force kTapShapes[id] where it divides the member
   const int s256 = env_int("TDN_WGRAD_S256", 8), s128 = env_int("TDN_WGRAD_S128", 4), s64 = env_int("TDN_WGRAD_S64", 2);
   const int s256f = env_int("TDN_WGRAD_S256F", 5);   // 256-channel members whose Cin does not divide the s256 tile
@@ -973,7 +980,9 @@ static int plan_group(const tdn_wgrad_item* items, int n, std::vector<ItemPlan>&
   for (int i = 0; i < n; ++i) {
     ItemPlan& g = plans[i];
     if (item_geometry(items[i], g)) return -1;
-    g.variant = (g.t9_ok && t9_mode != 0) ? 1 : 0;
+    // 64-channel tile only where the 128-channel one does not divide Cout (TDN_WGRAD9_64=0: such members stay with
+    // the tap-per-tile kernel)
+    g.variant = (g.t9_ok && t9_mode != 0) ? (g.Cout % 128 == 0 ? 1 : (t9_64 ? 2 : 0)) : 0;
     if (!g.variant && !g.grouped && g.Ktap != 32) {
       const int b = g.Cout % 256 == 0 ? 256 : (g.Cout % 128 == 0 ? 128 : 64);
       if (b < min_bmw) min_bmw = b;
@@ -983,11 +992,11 @@ static int plan_group(const tdn_wgrad_item* items, int n, std::vector<ItemPlan>&
     ItemPlan& g = plans[i];
     if (g.variant) {
       g.shape = -1;
-      g.tiles_co = g.Cout / 128;
+      g.tiles_co = g.Cout / (g.variant == 2 ? 64 : 128);
       g.tiles_k = g.Ktap / 64;
       g.step_clk = kT9StepClk;
       g.tmin = tmin_t9;
-      g.slots = 256;
+      g.slots = g.variant == 2 ? 512 : 256;   // 70 KB of LDS per 4-wave workgroup: two per CU
     } else {
       int bmw = g.Cout % 256 == 0 ? 256 : (g.Cout % 128 == 0 ? 128 : 64);
       if (uniform && bmw > min_bmw) bmw = min_bmw;
@@ -1097,17 +1106,17 @@ static int launch_tap(int shape, const WgGroup& grp, int nblocks, hipStream_t st
   }
 }
 
-template <bool F16>
+template <bool F16, int WMR>
 static int launch_t9(const WgGroup& grp, int nblocks, hipStream_t stream) {
-  constexpr size_t lds = 2 * (size_t)(64 * 256 + 3 * 72 * 128);
+  constexpr size_t lds = 2 * (size_t)(64 * (64 * WMR) + 3 * 72 * 128);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_group_kernel<F16>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_group_kernel<F16, WMR>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
     attr_set = true;
   }
-  TDN_LAUNCH((conv_wgrad9_group_kernel<F16>), dim3(nblocks), dim3(512), lds, stream, grp);
+  TDN_LAUNCH((conv_wgrad9_group_kernel<F16, WMR>), dim3(nblocks), dim3(WMR * 128), lds, stream, grp);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -1147,7 +1156,7 @@ extern "C" int tdn_wgrad_group_plan(const tdn_wgrad_item* items, int n, int dtyp
     const int64_t slab = g.direct ? 0 : (int64_t)g.splitk * g.Cout * g.Ktot * 4 / 1024;
     if (per_item) {
       int32_t* o = per_item + 8 * i;
-      o[0] = g.variant; o[1] = g.variant ? 128 : kTapShapes[g.shape].bmw; o[2] = g.variant ? 64 : kTapShapes[g.shape].bnw;
+      o[0] = g.variant; o[1] = g.variant ? (g.variant == 2 ? 64 : 128) : kTapShapes[g.shape].bmw; o[2] = g.variant ? 64 : kTapShapes[g.shape].bnw;
       o[3] = g.splitk; o[4] = g.mchunk; o[5] = g.direct; o[6] = g.blocks; o[7] = (int32_t)slab;
     }
     blocks += g.blocks;
@@ -1189,7 +1198,8 @@ extern "C" int tdn_wgrad_group(const tdn_wgrad_item* items, int n, void* workspa
     }
     const ItemPlan& g0 = plans[L[0]];
     int rc;
-    if (g0.variant) rc = dtype == TDN_F16 ? launch_t9<true>(grp, blk, stream) : launch_t9<false>(grp, blk, stream);
+    if (g0.variant == 2) rc = dtype == TDN_F16 ? launch_t9<true, 2>(grp, blk, stream) : launch_t9<false, 2>(grp, blk, stream);
+    else if (g0.variant) rc = dtype == TDN_F16 ? launch_t9<true, 4>(grp, blk, stream) : launch_t9<false, 4>(grp, blk, stream);
     else rc = dtype == TDN_F16 ? launch_tap<true>(g0.shape, grp, blk, stream) : launch_tap<false>(g0.shape, grp, blk, stream);
     if (rc) return rc;
   }
@@ -1257,7 +1267,7 @@ int tdn_wgrad_plan(int N, int H, int W, int Cin, int Cout, int k, int stride, in
   int64_t fl = 0;
   if (plan_group(&it, 1, plans, &fl)) return -1;
   const ItemPlan& w = plans[0];
-  o[0] = Cout; o[1] = w.Ktot; o[2] = w.M; o[3] = w.variant ? 128 : kTapShapes[w.shape].bmw;
+  o[0] = Cout; o[1] = w.Ktot; o[2] = w.M; o[3] = w.variant ? (w.variant == 2 ? 64 : 128) : kTapShapes[w.shape].bmw;
   o[4] = w.variant ? 64 : kTapShapes[w.shape].bnw; o[5] = 64;
   o[6] = w.tiles_co * w.tiles_k; o[7] = w.splitk; o[8] = 1; o[9] = 1; o[10] = k * k; o[11] = w.splitk;
   o[12] = w.mchunk; o[13] = w.Ho; o[14] = w.Wo; o[15] = w.M;

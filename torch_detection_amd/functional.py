@@ -521,8 +521,9 @@ def join_branches(device):
 def _t9_eligible(u, x_in):
     """Mirror of the library's choice of the nine-tap kernel (csrc/conv_wgrad.hip: item_geometry) — only used to put
     those members into a launch group (and side stream) of their own, never for correctness."""
-    return (u.k == 3 and u.stride == 1 and u.pad == 1 and u.groups == 1 and not u.is_stem and u.Cout % 128 == 0
-            and u.Cin % 64 == 0 and x_in.shape[2] >= 8)
+    return (u.k == 3 and u.stride == 1 and u.pad == 1 and u.groups == 1 and not u.is_stem and u.Cout % 64 == 0
+            and u.Cin % 64 == 0 and x_in.shape[2] >= 8 and
+            (u.Cout % 128 == 0 or os.environ.get('TDN_WGRAD9_64', '1') != '0'))
 
 
 class WgradQueue(object):
