@@ -192,6 +192,39 @@ typedef struct tdn_prep_item {
 } tdn_prep_item;
 int tdn_prepare_group(const tdn_prep_item* items, int n, int dtype, void* stream);
 
+/* ---- one residual Bottleneck per launch (models/backbone/resnet.py:97-119) ------------------
+ * Stride-1 Bottleneck without a downsample branch (resnet.py:110-118), C mid channels, 4C in / out:
+ *   forward   out1 = relu(bn1(conv1(in)));  out2 = relu(bn2(conv2(out1)));  out3 = relu(bn3(conv3(out2)) + in)
+ *   dgrad     out1 = mask1 . conv3^T(in);   out2 = mask2 . conv2^T(out1);   out3 = mask3 . (conv1^T(out2) + in)
+ *             (in = dL/d(block output before its ReLU), already masked; mask_k . v keeps v where mask_k > 0;
+ *              mask1 = saved conv2 output, mask2 = saved conv1 output, mask3 = the block input, NULL = no mask)
+ * in ONE launch: the intermediate tensors are handed from GEMM to GEMM through LDS (a workgroup owns 8 x 16 output
+ * pixels and recomputes conv1 on the one-pixel halo) and are only WRITTEN to out1 / out2 (the weight gradients read
+ * them later).  Bit-identical to the three tdn_conv2d_fwd / tdn_conv2d_dgrad launches it replaces.
+ *   forward: w1 / w2 / w3 = w_fwd of conv1 / conv2 / conv3, scale_k / shift_k their folded BN (NULL = 1 / 0)
+ *   dgrad:   w1 / w2 / w3 = w_dgrad of conv3 / conv2 / conv1 (BN scale folded), scale / shift unused
+ * tdn_bottleneck_supported: 1 if this build has a kernel for (C, stride, dilation); callers fall back to per-conv
+ * launches otherwise. */
+typedef struct tdn_bottleneck_args {
+  const void* in;       /* NHWC 16-bit [N][H][W][4C] */
+  const void* w1;       /* [C][1][1][4C] */
+  const void* w2;       /* [C][3][3][C] */
+  const void* w3;       /* [4C][1][1][C] */
+  const float* scale1; const float* shift1;   /* [C] */
+  const float* scale2; const float* shift2;   /* [C] */
+  const float* scale3; const float* shift3;   /* [4C] */
+  const void* mask1;    /* [N][H][W][C] */
+  const void* mask2;    /* [N][H][W][C] */
+  const void* mask3;    /* [N][H][W][4C] */
+  void* out1;           /* [N][H][W][C] */
+  void* out2;           /* [N][H][W][C] */
+  void* out3;           /* [N][H][W][4C] */
+  int32_t N, H, W, C;
+} tdn_bottleneck_args;
+int tdn_bottleneck_supported(int H, int W, int C, int stride, int dilation);
+int tdn_bottleneck_fwd(const tdn_bottleneck_args* a, int dtype, void* stream);
+int tdn_bottleneck_dgrad(const tdn_bottleneck_args* a, int dtype, void* stream);
+
 /* ---- grouped convolution (ResNeXt) -----------------------------------
  * conv3x3_group(..., groups=cardinality) of models/backbone/resnext.py:26-28,82-83: C channels in and out,
  * `groups` groups.  Computed in block-diagonal form: every 64-channel block of the output multiplies only the same

@@ -86,6 +86,19 @@ class AnchorLevel(ctypes.Structure):
 
 _AL = ctypes.POINTER(AnchorLevel)
 
+
+class BottleneckArgs(ctypes.Structure):
+    """Mirror of ``tdn_bottleneck_args`` (include/tdn.h)."""
+    _fields_ = [("in_", c_void_p), ("w1", c_void_p), ("w2", c_void_p), ("w3", c_void_p),
+                ("scale1", c_void_p), ("shift1", c_void_p), ("scale2", c_void_p), ("shift2", c_void_p),
+                ("scale3", c_void_p), ("shift3", c_void_p),
+                ("mask1", c_void_p), ("mask2", c_void_p), ("mask3", c_void_p),
+                ("out1", c_void_p), ("out2", c_void_p), ("out3", c_void_p),
+                ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32)]
+
+
+_BA = ctypes.POINTER(BottleneckArgs)
+
 # name -> (restype, argtypes); must list every symbol of include/tdn.h (tests/test_abi.py checks this)
 SIGNATURES = {
     "tdn_last_error": (ctypes.c_char_p, []),
@@ -136,6 +149,9 @@ SIGNATURES = {
                                      ctypes.POINTER(c_float), c_void_p]),
     "tdn_pack_gconv_weight": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p, c_int, c_void_p]),
+    "tdn_bottleneck_supported": (c_int, [c_int] * 5),
+    "tdn_bottleneck_fwd": (c_int, [_BA, c_int, c_void_p]),
+    "tdn_bottleneck_dgrad": (c_int, [_BA, c_int, c_void_p]),
     "tdn_gconv2d_fwd": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
     "tdn_gconv2d_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
     "tdn_gconv2d_wgrad_workspace": (c_i64, [c_int] * 8),

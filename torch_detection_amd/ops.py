@@ -259,6 +259,68 @@ def conv2d_dgrad(g, w_dgrad, in_hw, k, stride, pad, addend=None, addend_mode=ADD
     return dx
 
 
+def bottleneck_supported(H, W, C, stride=1, dilation=1):
+    """Does this build have a one-launch kernel for a stride-1 Bottleneck with C mid channels?"""
+    return bool(_lib.load().tdn_bottleneck_supported(int(H), int(W), int(C), int(stride), int(dilation)))
+
+
+def _bottleneck_args(name, a, w1, w2, w3, affine, masks, outs):
+    _chk_act(a, "in")
+    N, H, W, C4 = a.shape
+    C = C4 // 4
+    if C * 4 != C4:
+        raise ValueError("%s: %d input channels are not 4 x the mid channels" % (name, C4))
+    for w, shp, nm in ((w1, (C, 1, 1, C4), "w1"), (w2, (C, 3, 3, C), "w2"), (w3, (C4, 1, 1, C), "w3")):
+        if w.dtype != a.dtype or tuple(w.shape) != shp or not w.is_contiguous() or not w.is_cuda:
+            raise ValueError("%s: %s must be %s %s contiguous, got %s %s" % (name, nm, a.dtype, shp, w.dtype,
+                                                                              tuple(w.shape)))
+    o1, o2, o3 = outs if outs is not None else (None, None, None)
+    o1 = torch.empty(N, H, W, C, dtype=a.dtype, device=a.device) if o1 is None else _out_buffer(o1, (N, H, W, C), a.dtype, name)
+    o2 = torch.empty(N, H, W, C, dtype=a.dtype, device=a.device) if o2 is None else _out_buffer(o2, (N, H, W, C), a.dtype, name)
+    o3 = torch.empty(N, H, W, C4, dtype=a.dtype, device=a.device) if o3 is None else _out_buffer(o3, (N, H, W, C4), a.dtype, name)
+    args = _lib.BottleneckArgs()
+    args.in_, args.w1, args.w2, args.w3 = a.data_ptr(), w1.data_ptr(), w2.data_ptr(), w3.data_ptr()
+    if affine is not None:
+        for i, (v, n) in enumerate(zip(affine, (C, C, C, C, C4, C4))):
+            _chk_vec(v, "affine[%d]" % i, n)
+        sc1, sh1, sc2, sh2, sc3, sh3 = affine
+        for fld, v in (("scale1", sc1), ("shift1", sh1), ("scale2", sc2), ("shift2", sh2), ("scale3", sc3),
+                       ("shift3", sh3)):
+            setattr(args, fld, v.data_ptr() if v is not None else None)
+    if masks is not None:
+        for fld, m, n in zip(("mask1", "mask2", "mask3"), masks, (C, C, C4)):
+            if m is not None:
+                _chk_act(m, fld, n, a.dtype)
+                if tuple(m.shape[:3]) != (N, H, W):
+                    raise ValueError("%s: %s has shape %s, expected (%d, %d, %d, %d)" % (name, fld, tuple(m.shape), N, H, W, n))
+                setattr(args, fld, m.data_ptr())
+    args.out1, args.out2, args.out3 = o1.data_ptr(), o2.data_ptr(), o3.data_ptr()
+    args.N, args.H, args.W, args.C = N, H, W, C
+    return args, (o1, o2, o3)
+
+
+def bottleneck_fwd(x, w1, w2, w3, affine, outs=None):
+    """Stride-1 Bottleneck (resnet.py:97-119) in one launch: returns (h1, h2, out).  ``affine`` = (scale1, shift1,
+    scale2, shift2, scale3, shift3) of the folded BNs; w_k = w_fwd packs of conv1 / conv2 / conv3."""
+    args, o = _bottleneck_args("bottleneck_fwd", x, w1, w2, w3, affine, None, outs)
+    _lib.check(_lib.load().tdn_bottleneck_fwd(ctypes.byref(args), dtype_code(x.dtype), _lib.stream_ptr()),
+               "tdn_bottleneck_fwd")
+    return o
+
+
+def bottleneck_dgrad(g, w3d, w2d, w1d, masks, outs=None):
+    """Input-gradient chain of the same block in one launch: returns (g2, g1, dx) with g2 = mask(h2) . conv3^T(g),
+    g1 = mask(h1) . conv2^T(g2), dx = mask(x) . (conv1^T(g1) + g).  ``masks`` = (h2, h1, x | None); w_kd = w_dgrad packs
+    of conv3 / conv2 / conv1."""
+    C = g.shape[3] // 4
+    if tuple(w3d.shape) != (C, 1, 1, 4 * C) or tuple(w1d.shape) != (4 * C, 1, 1, C):
+        raise ValueError("bottleneck_dgrad: w_dgrad packs have shapes %s / %s" % (tuple(w3d.shape), tuple(w1d.shape)))
+    args, o = _bottleneck_args("bottleneck_dgrad", g, w3d, w2d, w1d, None, masks, outs)
+    _lib.check(_lib.load().tdn_bottleneck_dgrad(ctypes.byref(args), dtype_code(g.dtype), _lib.stream_ptr()),
+               "tdn_bottleneck_dgrad")
+    return o
+
+
 _ws_cache = {}
 _ws_retired = []   # outgrown workspaces stay referenced: a side stream may still be running kernels that use them
 
