@@ -812,6 +812,24 @@ class SeqNet(object):
         return ps
 
 
+def _block_fusable(b, C4):
+    """Stride-1 Bottleneck without a downsample branch, plain convs (+ folded eval-mode BN), ReLU activations, and a
+    one-launch kernel for its width in this build (csrc/conv_block.hip): conv1 -> conv2 -> conv3 + residual run as
+    ONE launch, forward (ops.bottleneck_fwd) and input-gradient chain (ops.bottleneck_dgrad).  TDN_BLOCK_FUSE=0
+    keeps the per-conv launches (A/B runs, and the reference side of tests/test_gpu_block.py)."""
+    if b.kind != 'bottleneck' or b.ud is not None or b.stride != 1 or os.environ.get('TDN_BLOCK_FUSE', '1') == '0':
+        return False
+    u1, u2, u3 = b.u1, b.u2, b.u3
+    for u in (u1, u2, u3):
+        if u.gn or u.bnt or u.groups != 1 or u.act6 or u.bias_and_norm or u.is_stem or u.stride != 1:
+            return False
+    C = u1.Cout
+    if not (u1.k == 1 and u3.k == 1 and u2.k == 3 and u2.pad == 1 and u1.Cin == C4 and u3.Cout == C4 and
+            C4 == 4 * C and u2.Cin == C and u2.Cout == C and u3.Cin == C):
+        return False
+    return ops.bottleneck_supported(1, 1, C)
+
+
 def _block_fwd(x, b, bufs=None):
     """One residual block.  ``bufs`` = caller-provided (h1, h2, out, res) outputs — one image's slices of batch
     tensors when the images of a batch run as separate chains (ImageSplit); everything then stays on the routed
@@ -820,6 +838,12 @@ def _block_fwd(x, b, bufs=None):
     o1 = o2 = o3 = ores = None
     if bufs is not None:
         o1, o2, o3, ores = bufs
+    if _block_fusable(b, x.shape[3]):
+        u1, u2, u3 = b.u1, b.u2, b.u3
+        h1, h2, out = ops.bottleneck_fwd(x, u1.w_fwd, u2.w_fwd, u3.w_fwd,
+                                         (u1.scale, u1.shift, u2.scale, u2.shift, u3.scale, u3.shift),
+                                         outs=(o1, o2, o3) if bufs is not None else None)
+        return out, (x, h1, h2, out)
     if b.ud is not None:
         if bufs is not None:
             res = unit_fwd(b.ud, x, relu=False, out=ores)
@@ -940,6 +964,20 @@ def _blocks_fwd_split(blocks, cur):
     return x, saved
 
 
+def _block_dgrad_fused(b, saved, g, mask_src, outs=None):
+    """The three input gradients of a fusable block in one launch (g2, g1, dx); with DEBUG_BWD set the launch is
+    recorded as the three dgrad launches it replaces — their operands and results all exist in HBM — so the in-situ
+    parity checks (tests/parity_util.py) recompute every conv of the fused launch like any other."""
+    x, h1, h2, out = saved
+    u1, u2, u3 = b.u1, b.u2, b.u3
+    g2, g1, dx = ops.bottleneck_dgrad(g, u3.w_dgrad, u2.w_dgrad, u1.w_dgrad, (h2, h1, mask_src), outs=outs)
+    if DEBUG_BWD is not None:
+        DEBUG_BWD.append(('dgrad', u3, g, _hw(h2), None, ADD_NONE, h2, g2))
+        DEBUG_BWD.append(('dgrad', u2, g2, _hw(h1), None, ADD_NONE, h1, g1))
+        DEBUG_BWD.append(('dgrad', u1, g1, _hw(x), g, ADD_SAME, mask_src, dx))
+    return g2, g1, dx
+
+
 def _block_bwd(b, saved, g, extra, mask_src, need_dx, wq=None):
     """g: gradient w.r.t. the block's pre-ReLU output, already masked by (out > 0).
     extra: external gradient w.r.t. the block INPUT to fold in (e.g. the FPN's gradient of a stage output).
@@ -948,6 +986,12 @@ def _block_bwd(b, saved, g, extra, mask_src, need_dx, wq=None):
     x, h1, h2, out = saved
     grads = {}
     t, br = None, None
+    if need_dx and extra is None and _block_fusable(b, x.shape[3]):
+        g2, g1, dx = _block_dgrad_fused(b, saved, g, mask_src)
+        grads[b.u3] = unit_wgrad(b.u3, h2, g, queue=wq)
+        grads[b.u2] = unit_wgrad(b.u2, h1, g2, queue=wq)
+        grads[b.u1] = unit_wgrad(b.u1, x, g1, queue=wq)
+        return dx, grads
     if need_dx and b.ud is not None:
         with branch(g.device, b.ud, (g, extra) if extra is not None else (g,)) as br:
             t = unit_dgrad(b.ud, g, _hw(x), extra, ADD_SAME)   # beside the conv3 -> conv2 dgrads of the main path
@@ -990,11 +1034,17 @@ def _block_bwd_chains(b, saved, g, extra, mask_src, wq, pool, cuts):
     g1 = new_like(h1)
     dx = new_like(x)
     t = new_like(x) if b.ud is not None else g
+    fused = extra is None and _block_fusable(b, x.shape[3])
     for i, st in enumerate(pool[:len(cuts) - 1]):
         a, e = cuts[i], cuts[i + 1]
         prev = _lib.set_stream_override(st.cuda_stream)
         try:
             gi = g[a:e]
+            if fused:
+                _block_dgrad_fused(b, (x[a:e], h1[a:e], h2[a:e], None), gi,
+                                   mask_src[a:e] if mask_src is not None else None,
+                                   outs=(g2[a:e], g1[a:e], dx[a:e]))
+                continue
             if b.ud is not None:
                 unit_dgrad(b.ud, gi, _hw(x), extra[a:e] if extra is not None else None, ADD_SAME, out=t[a:e])
             if bott:
