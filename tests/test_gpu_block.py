@@ -154,7 +154,8 @@ def test_block_dgrad(ops, generic_tiles, N, H, W, dtype, with_mask3):
     assert max_rel(dx.float().cpu(), cx) <= TOL + ulp
 
 
-def test_block_layer1_geometry(ops, generic_tiles):
+@pytest.mark.parametrize("rep", range(3))
+def test_block_layer1_geometry(ops, generic_tiles, rep):
     """BASELINE geometry of layer1 (one image, 200 x 336, 64 mid channels): bit for bit against the per-conv path."""
     N, H, W, C, dtype = 1, 200, 336, 64, torch.bfloat16
     x, w1, w2, w3, aff = _case(N, H, W, C, dtype, 4242)
@@ -166,5 +167,8 @@ def test_block_layer1_geometry(ops, generic_tiles):
     r2 = ops.conv2d_fwd(r1, w2g, 3, 1, 1, affg[2], affg[3], relu=True)
     r3 = ops.conv2d_fwd(r2, w3g, 1, 1, 0, affg[4], affg[5], xg, ops.ADD_SAME, True)
     torch.cuda.synchronize()
-    for a, b in ((h1, r1), (h2, r2), (out, r3)):
-        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    for name, a, b in (("h1", h1, r1), ("h2", h2, r2), ("out", out, r3)):
+        ne = (a.view(torch.int16) != b.view(torch.int16))
+        if bool(ne.any()):
+            idx = ne.nonzero()[:8].tolist()
+            raise AssertionError("%s: %d of %d elements differ, first at (n, y, x, c) %s" % (name, int(ne.sum()), a.numel(), idx))

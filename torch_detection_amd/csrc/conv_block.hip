@@ -53,26 +53,33 @@ struct BlockParams {
   int tiles_x, tiles_y, ntiles, nwg_pad;
 };
 
+// Workgroup barrier that is also a compiler barrier for memory operations and retires this wave's LDS reads first.
+// The raw __builtin_amdgcn_s_barrier() orders nothing for the compiler: a ds_write into a region other waves were
+// still reading before the barrier (H1 over ring slots 2 / 3, H2 over H1) may be hoisted above it — seen as a
+// timing-dependent mismatch at 525 co-resident workgroups, never at small grids.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool BWD, bool F16>
 __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int C = 64, C4 = 256, TH = 8, TW = 16, HWD = TW + 2, PH = (TH + 2) * HWD /* 180 */, PHP = 192;
-  constexpr int ROWB = 128;
-  constexpr int X_BYTES = PHP * ROWB;          // 24576: one 64-channel K-step of the haloed patch
-  constexpr int W1_BYTES = C * ROWB;           //  8192
-  constexpr int STAGE1 = X_BYTES + W1_BYTES;   // 32768; phase 1 ring: [0, 65536)
-  constexpr int TAP_BYTES = C * ROWB;          //  8192
-  constexpr int W2_LO = 24576;                 // taps 2..6: [24576, 65536)   (issued after phase 1)
-  constexpr int W2_HI = 65536;                 // taps 0, 1 (issued at kernel start), later taps 7, 8: [65536, 81920)
-  constexpr int W3_OFF = 24576;                // [24576, 57344): issued once taps 2..6 are consumed
-  // H1 lives at [0, 24576) during phase 2, H2 at [0, 16384) during phase 3
+  constexpr int ROWB = 128;                    // H1 / H2 / conv2 / conv3 weight rows: 64 channels
+  // ---- LDS map (80 KB; two workgroups per CU) ----
+  // phase 1: ring of four 32-channel K-steps, S(s) = s * 16384: X[192 rows][64 B] (12 KB) + W1[64 rows][64 B] (4 KB)
+  constexpr int SLOT = 16384, XB32 = PHP * 64;
+  constexpr int T_OFF = 65536;                 // conv2 taps 0, 1 (issued at kernel start), later taps 7, 8
+  constexpr int TAP_BYTES = C * ROWB;          // 8192
+  // conv2 taps 2..6 at [0, 40960): issued into the ring slots as phase 1 releases them (they take the place of the
+  // K-steps 8, 9, 10 the ring would prefetch next, so the counted vmcnt stays uniform)
+  constexpr int H1_OFF = 40960;                // [40960, 65536): written once the ring is drained
+  constexpr int W3_OFF = 0;                    // [0, 32768): issued once taps 2..6 are consumed
+  constexpr int H2_OFF = 40960;                // [40960, 57344): written once H1 is dead
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
-  const int lrow = lane >> 3, lchunk = lane & 7;
 
   const int bid = blockIdx.x;
   const int tile = (bid & 7) * (p.nwg_pad >> 3) + (bid >> 3);   // XCD x owns a contiguous run of tiles (shared halos)
@@ -85,116 +92,138 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   const int y0 = ty * TH, x0 = tx * TW;
   const int64_t img_pix0 = (int64_t)img * H * W;
 
-  const char* zero = (const char*)g_zero_page + lchunk * 16;
+  auto swz_w8 = [](int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); };    // 128-B rows, 8 channels per lane
+  auto swz_w16 = [](int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); };   // 128-B rows, 16 channels per lane
 
-  auto swz_w8 = [](int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); };    // 8 consecutive channels per lane
-  auto swz_w16 = [](int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); };   // 16
-
-  // ---- conv2 weights, taps 0 and 1: nothing else uses [65536, 81920) during phase 1 ----
-  auto load_tap = [&](int t, int dst_off) {
+  // ---- conv2 weight taps: 64 rows x 128 B each, two LDS-DMA instructions per wave ----
+  const int lrow8 = lane >> 3, lchunk8 = lane & 7;
+  auto tap_off = [](int t) { return t < 2 ? T_OFF + t * TAP_BYTES : (t < 7 ? (t - 2) * TAP_BYTES : T_OFF + (t - 7) * TAP_BYTES); };
+  auto load_tap = [&](int t) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int g8 = it * 4 + wave;
-      const int n = g8 * 8 + lrow;
-      const char* src = (const char*)p.w2 + ((int64_t)n * (9 * C) + t * C) * 2 + ((lchunk ^ swz_w8(n)) * 16);
-      glds16_async(src, smem + dst_off + g8 * 8 * ROWB);
+      const int n = g8 * 8 + lrow8;
+      const char* src = (const char*)p.w2 + ((int64_t)n * (9 * C) + t * C) * 2 + ((lchunk8 ^ swz_w8(n)) * 16);
+      glds16_async(src, smem + tap_off(t) + g8 * 8 * ROWB);
     }
   };
-  load_tap(0, W2_HI);
-  load_tap(1, W2_HI + TAP_BYTES);
+  load_tap(0);
+  load_tap(1);
 
-  // ---- phase 1 loader state: 6 patch rows and 2 weight rows per lane and K-step ----
-  const char* xsrc[6];
+  // ---- phase 1 loader state: 32-channel K-steps, 64-byte rows, 16 rows per LDS-DMA instruction ----
+  // 64-byte rows: four rows per 256-byte bank line; chunk swizzle f(row) = (4 - ((row >> 2) & 3)) & 3 keeps the
+  // ds_read_b128 lane groups (rows {0-3, 12-15} with k-chunk kq, rows {4-11} with kq + 1) on 16 distinct slots
+  const int lrow16 = lane >> 2, lchunk4 = lane & 3;
+  const char* zero = (const char*)g_zero_page + lchunk4 * 16;
+  const char* xsrc[3];
   unsigned xok = 0;
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {
-    const int R = (it * 4 + wave) * 8 + lrow;
+  for (int it = 0; it < 3; ++it) {
+    const int R = (it * 4 + wave) * 16 + lrow16;
     const int hy = R / HWD, hx = R - hy * HWD;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
-    const int swz = (R >> 1) & 7;
-    xsrc[it] = (const char*)p.a + ((img_pix0 + (int64_t)y * W + x) * C4 + ((lchunk ^ swz) * 8)) * 2;
+    const int swz = (4 - ((R >> 2) & 3)) & 3;
+    xsrc[it] = (const char*)p.a + ((img_pix0 + (int64_t)y * W + x) * C4 + ((lchunk4 ^ swz) * 8)) * 2;
     xok |= ok ? (1u << it) : 0u;
   }
-  const char* w1src[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int n = (it * 4 + wave) * 8 + lrow;
-    w1src[it] = (const char*)p.w1 + ((int64_t)n * C4) * 2 + ((lchunk ^ swz_w8(n)) * 16);
+  const char* w1src;
+  {
+    const int n = wave * 16 + lrow16;
+    w1src = (const char*)p.w1 + ((int64_t)n * C4) * 2 + ((lchunk4 ^ ((4 - ((n >> 3) & 3)) & 3)) * 16);
   }
-  auto load_stage1 = [&](int kc) {
-    char* sX = smem + (kc & 1) * STAGE1;
-    char* sW = sX + X_BYTES;
+  auto load_step = [&](int kc) {   // K-step kc (32 channels) into ring slot kc & 3
+    char* sX = smem + (kc & 3) * SLOT;
 #pragma unroll
-    for (int it = 0; it < 6; ++it)
-      glds16_async((xok >> it) & 1u ? xsrc[it] + kc * 128 : zero, sX + (it * 4 + wave) * 8 * ROWB);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) glds16_async(w1src[it] + kc * 128, sW + (it * 4 + wave) * 8 * ROWB);
+    for (int it = 0; it < 3; ++it)
+      glds16_async((xok >> it) & 1u ? xsrc[it] + kc * 64 : zero, sX + (it * 4 + wave) * 1024);
+    glds16_async(w1src + kc * 64, sX + XB32 + wave * 1024);
   };
 
   // ---- fragment read constants ----
-  const int f_rd = (fr >> 1) & 7;                               // swizzle of a pixel row whose index is fr (mod 16)
-  const int f_rd_w = ((fr & 3) >> 1) | ((fr >> 2) << 1);        // swizzle of this lane's weight rows
-  const int wrow8 = (wn * 32 + (fr >> 2) * 8 + (fr & 3)) * ROWB;     // + 4i rows: 8 consecutive channels per lane
+  const int f_rd = (fr >> 1) & 7;                               // 128-B rows: swizzle of a pixel row congruent to fr (mod 16)
+  const int f_rd_w = ((fr & 3) >> 1) | ((fr >> 2) << 1);        // 128-B rows: swizzle of this lane's weight rows
+  const int f_rd32 = (4 - (fr >> 2)) & 3;                       // 64-B rows: pixel rows and weight rows alike
+  const int wrow8 = wn * 32 + (fr >> 2) * 8 + (fr & 3);         // + 4i: this lane's weight row of fragment i (8 ch / lane)
   // even / odd deal of the 3x3 phase: MFMA column r <-> pixel pi(r) of the 16-pixel tile row
   const int pi = fr < 4 ? 2 * fr : (fr >= 12 ? 2 * (fr - 8) : 2 * (fr - 4) + 1);
-
-  // ================= phase 1: H1[halo][C] =================
-  f32x4_t acc1[2][6];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) acc1[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  load_stage1(0);
-#pragma unroll 1
-  for (int kc = 0; kc < C4 / 64; ++kc) {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // step kc landed; the other stage is free again
-    if (kc + 1 < C4 / 64) load_stage1(kc + 1);
-    const char* sX = smem + (kc & 1) * STAGE1 + (wm * 96 + fr) * ROWB;
-    const char* sW = smem + (kc & 1) * STAGE1 + X_BYTES + wrow8;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t wf[2], xf[6];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) wf[i] = lds_read_b128(sW + i * 4 * ROWB + (((kk * 4 + fq) ^ f_rd_w) * 16));
-#pragma unroll
-      for (int j = 0; j < 6; ++j) xf[j] = lds_read_b128(sX + j * 16 * ROWB + (((kk * 4 + fq) ^ f_rd) * 16));
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) acc1[i][j] = mfma16<F16>(wf[i], xf[j], acc1[i][j]);
-    }
-  }
-  __builtin_amdgcn_s_barrier();   // b0: every wave is done reading the ring
-  // conv2 taps 2..6 into [24576, 65536): lands while the epilogue below runs
-#pragma unroll
-  for (int t = 2; t < 7; ++t) load_tap(t, W2_LO + (t - 2) * TAP_BYTES);
-
   const int cb8 = wn * 32 + fq * 8;     // this lane's 8 consecutive channels of the C-wide outputs
-  {
-    f32x4_t sc[2], sh[2];
+
+  // per-channel affine of an epilogue: folded BN in the forward pass (NULL: 1 / 0); the backward pass has none — the
+  // same fma(acc, 1, 0) as conv_gemm_kernel computes for a NULL scale / shift, with constant operands
+  auto load_affine = [&](const float* scp, const float* shp, int ch, f32x4_t& sc, f32x4_t& sh) {
+    sc = (!BWD && scp) ? *(const f32x4_t*)(scp + ch) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+    sh = (!BWD && shp) ? *(const f32x4_t*)(shp + ch) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
+  f32x4_t sc1v[2], sh1v[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      sc[i] = p.sc1 ? *(const f32x4_t*)(p.sc1 + cb8 + 4 * i) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
-      sh[i] = p.sh1 ? *(const f32x4_t*)(p.sh1 + cb8 + 4 * i) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
+  for (int i = 0; i < 2; ++i) load_affine(p.sc1, p.sh1, cb8 + 4 * i, sc1v[i], sh1v[i]);
+  // backward: ReLU-mask operands of the phase 1 epilogue, requested before the K loop
+  bf16x8_t mk1[6];
+  if constexpr (BWD) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int R = wm * 96 + j * 16 + fr;
       const int hy = R / HWD, hx = R - hy * HWD;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
-      const int64_t pix = img_pix0 + (int64_t)y * W + x;
+      mk1[j] = (ok && p.m1) ? *(const bf16x8_t*)(p.m1 + (img_pix0 + (int64_t)y * W + x) * C + cb8) : bf16x8_t{};
+    }
+  }
+
+  // ================= phase 1: H1[halo][C], eight 32-deep K-steps through a four-slot ring =================
+  f32x4_t acc1[2][6];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc1[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  load_step(0);
+  load_step(1);
+  load_step(2);
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc) {
+    // every issue slot below is 4 LDS-DMA instructions per wave (a K-step, or two conv2 taps): two of them younger
+    // than K-step kc are in flight here
+    // lgkmcnt(0): with the loop unrolled the scheduler sinks the MFMAs — and the waits of their fragment reads — below
+    // the barrier; a read still queued in the LDS pipe can then be overtaken by the LDS-DMA another wave issues into
+    // the same ring slot right behind the barrier (seen: 1 KiB pieces of stale data in ~10 of 525 tiles per launch)
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // K-step kc landed; slot (kc - 1) & 3 is free
+    if (kc + 3 < 8) load_step(kc + 3);
+    else if (kc == 5) { load_tap(2); load_tap(3); }
+    else if (kc == 6) { load_tap(4); load_tap(5); }
+    else { load_tap(6); }
+    const char* sX = smem + (kc & 3) * SLOT + (wm * 96 + fr) * 64 + ((fq ^ f_rd32) * 16);
+    const char* sW = smem + (kc & 3) * SLOT + XB32 + wrow8 * 64 + ((fq ^ f_rd32) * 16);
+    bf16x8_t wf[2], xf[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wf[i] = lds_read_b128(sW + i * 4 * 64);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) xf[j] = lds_read_b128(sX + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc1[i][j] = mfma16<F16>(wf[i], xf[j], acc1[i][j]);
+  }
+  lds_barrier();   // b0: every wave is done reading the ring
+
+  bf16x8_t o1v[6];
+  unsigned st1 = 0;               // bit j: fragment j of this lane is an interior pixel inside the image -> stored
+  {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int R = wm * 96 + j * 16 + fr;
+      const int hy = R / HWD, hx = R - hy * HWD;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
       f32x4_t v[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) v[i] = acc1[i][j] * sc[i] + sh[i];
+      for (int i = 0; i < 2; ++i) v[i] = acc1[i][j] * sc1v[i] + sh1v[i];
       if constexpr (BWD) {
-        if (p.m1 && ok) {
-          const bf16x8_t mk = *(const bf16x8_t*)(p.m1 + pix * C + cb8);
+        if (p.m1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[0][e] = (elem_to_f32<F16>(mk[e]) > 0.f) ? v[0][e] : 0.f;
-            v[1][e] = (elem_to_f32<F16>(mk[4 + e]) > 0.f) ? v[1][e] : 0.f;
+            v[0][e] = (elem_to_f32<F16>(mk1[j][e]) > 0.f) ? v[0][e] : 0.f;
+            v[1][e] = (elem_to_f32<F16>(mk1[j][4 + e]) > 0.f) ? v[1][e] : 0.f;
           }
         }
       } else {
@@ -209,12 +238,31 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
         o[e] = f32_to_elem<F16>(ok ? v[0][e] : 0.f);       // zero padding of the 3x3 conv: outside the image H1 is 0
         o[4 + e] = f32_to_elem<F16>(ok ? v[1][e] : 0.f);
       }
-      *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + R * ROWB + (((wn * 4 + fq) ^ ((R >> 1) & 7)) * 16)) = o;
-      if (ok && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW) *(bf16x8_t*)(p.o1 + pix * C + cb8) = o;
+      *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + H1_OFF + R * ROWB + (((wn * 4 + fq) ^ ((R >> 1) & 7)) * 16)) = o;
+      o1v[j] = o;
+      st1 |= (ok && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW) ? (1u << j) : 0u;
     }
   }
-  // b1: H1 complete (LDS writes of every wave), taps 0 / 1 landed long ago (waited with phase 1's loads)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // b1: H1 complete (LDS writes of every wave), taps 2..6 landed (taps 0 / 1 long ago)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // h1 / g2 to HBM: behind the barrier, so that nobody waits for the stores
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    if ((st1 >> j) & 1u) {
+      const int R = wm * 96 + j * 16 + fr;
+      const int hy = R / HWD, hx = R - hy * HWD;
+      *(bf16x8_t*)(p.o1 + (img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx)) * C + cb8) = o1v[j];
+    }
+  }
+  // backward: mask operands of the phase 2 epilogue
+  bf16x8_t mk2[4];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + wm * 4 + j, x = x0 + pi;
+      mk2[j] = (p.m2 && y < H && x < W) ? *(const bf16x8_t*)(p.m2 + (img_pix0 + (int64_t)y * W + x) * C + cb8) : bf16x8_t{};
+    }
+  }
 
   // ================= phase 2: H2[8x16][C] =================
   f32x4_t acc2[2][4];
@@ -222,10 +270,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  auto tap_compute = [&](int t, int slot_off) {
+  auto tap_compute = [&](int t) {
     const int ky = t / 3, kx = t - ky * 3;
     const int oy = BWD ? 2 - ky : ky, ox = BWD ? 2 - kx : kx;   // patch offset of the tap (build_fwd / build_dgrad order)
-    const char* sW = smem + slot_off + wrow8;
+    const char* sW = smem + tap_off(t) + wrow8 * ROWB;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8_t wf[2], xf[4];
@@ -234,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int R = (wm * 4 + j + oy) * HWD + pi + ox;
-        xf[j] = lds_read_b128(smem + R * ROWB + (((kk * 4 + fq) ^ ((R >> 1) & 7)) * 16));
+        xf[j] = lds_read_b128(smem + H1_OFF + R * ROWB + (((kk * 4 + fq) ^ ((R >> 1) & 7)) * 16));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -242,47 +290,63 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
         for (int j = 0; j < 4; ++j) acc2[i][j] = mfma16<F16>(wf[i], xf[j], acc2[i][j]);
     }
   };
-  tap_compute(0, W2_HI);
-  tap_compute(1, W2_HI + TAP_BYTES);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // b2: taps 2..6 landed; [65536, 81920) is free
-  load_tap(7, W2_HI);
-  load_tap(8, W2_HI + TAP_BYTES);
+  tap_compute(0);
+  tap_compute(1);
+  lds_barrier();   // b2: [65536, 81920) is free
+  load_tap(7);
+  load_tap(8);
 #pragma unroll
-  for (int t = 2; t < 7; ++t) tap_compute(t, W2_LO + (t - 2) * TAP_BYTES);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // b3: taps 7, 8 landed; [24576, 65536) is free
-  // conv3 weights [4C][C] into [24576, 57344) while taps 7 and 8 are multiplied
+  for (int t = 2; t < 7; ++t) tap_compute(t);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // b3: taps 7, 8 landed; [0, 40960) is free
+  // conv3 weights [4C][C] into [0, 32768) while taps 7 and 8 are multiplied
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int g8 = it * 4 + wave;
-    const int n = g8 * 8 + lrow;
-    glds16_async((const char*)p.w3 + (int64_t)n * C * 2 + ((lchunk ^ swz_w16(n)) * 16), smem + W3_OFF + g8 * 8 * ROWB);
+    const int n = g8 * 8 + lrow8;
+    glds16_async((const char*)p.w3 + (int64_t)n * C * 2 + ((lchunk8 ^ swz_w16(n)) * 16), smem + W3_OFF + g8 * 8 * ROWB);
   }
-  tap_compute(7, W2_HI);
-  tap_compute(8, W2_HI + TAP_BYTES);
-  __builtin_amdgcn_s_barrier();   // b4: every wave is done with H1
-  {
-    f32x4_t sc[2], sh[2];
+  // addend (and mask) of the first 128 output channels: requested now, consumed after phase 3's first pass
+  const int chw = wn * 64 + fq * 16;       // + nc * 128: this lane's 16 consecutive output channels
+  bool okp[4];
+  int64_t pixp[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      sc[i] = p.sc2 ? *(const f32x4_t*)(p.sc2 + cb8 + 4 * i) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
-      sh[i] = p.sh2 ? *(const f32x4_t*)(p.sh2 + cb8 + 4 * i) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
+  for (int j = 0; j < 4; ++j) {
+    const int y = y0 + wm * 4 + j, x = x0 + fr;
+    okp[j] = (y < H) && (x < W);
+    pixp[j] = img_pix0 + (int64_t)y * W + x;
+  }
+  bf16x8_t ad[4][2], mk3[4][2];
+  auto load_addend = [&](int nc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ad[j][h] = okp[j] ? *(const bf16x8_t*)(p.a + pixp[j] * C4 + nc * 128 + chw + h * 8) : bf16x8_t{};
+        if constexpr (BWD)
+          mk3[j][h] = (okp[j] && p.m3) ? *(const bf16x8_t*)(p.m3 + pixp[j] * C4 + nc * 128 + chw + h * 8) : bf16x8_t{};
+      }
+  };
+  load_addend(0);
+  f32x4_t sc2v[2], sh2v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) load_affine(p.sc2, p.sh2, cb8 + 4 * i, sc2v[i], sh2v[i]);
+  tap_compute(7);
+  tap_compute(8);
+  lds_barrier();   // b4: every wave is done with H1
+  bf16x8_t o2v[4];
+  f32x4_t sc3v[4], sh3v[4];
+  {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int yy = wm * 4 + j;
-      const int y = y0 + yy, x = x0 + pi;
-      const bool ok = (y < H) && (x < W);
-      const int64_t pix = img_pix0 + (int64_t)y * W + x;
       f32x4_t v[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) v[i] = acc2[i][j] * sc[i] + sh[i];
+      for (int i = 0; i < 2; ++i) v[i] = acc2[i][j] * sc2v[i] + sh2v[i];
       if constexpr (BWD) {
-        if (p.m2 && ok) {
-          const bf16x8_t mk = *(const bf16x8_t*)(p.m2 + pix * C + cb8);
+        if (p.m2) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[0][e] = (elem_to_f32<F16>(mk[e]) > 0.f) ? v[0][e] : 0.f;
-            v[1][e] = (elem_to_f32<F16>(mk[4 + e]) > 0.f) ? v[1][e] : 0.f;
+            v[0][e] = (elem_to_f32<F16>(mk2[j][e]) > 0.f) ? v[0][e] : 0.f;
+            v[1][e] = (elem_to_f32<F16>(mk2[j][4 + e]) > 0.f) ? v[1][e] : 0.f;
           }
         }
       } else {
@@ -297,40 +361,27 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
         o[e] = f32_to_elem<F16>(v[0][e]);
         o[4 + e] = f32_to_elem<F16>(v[1][e]);
       }
-      const int pr = yy * TW + pi;
-      *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + pr * ROWB + (((wn * 4 + fq) ^ ((pr >> 1) & 7)) * 16)) = o;
-      if (ok) *(bf16x8_t*)(p.o2 + pix * C + cb8) = o;
+      const int pr = (wm * 4 + j) * TW + pi;
+      *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + H2_OFF + pr * ROWB + (((wn * 4 + fq) ^ ((pr >> 1) & 7)) * 16)) = o;
+      o2v[j] = o;
     }
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, chw + 4 * i, sc3v[i], sh3v[i]);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // b5: H2 complete, conv3 weights landed
 
   // ================= phase 3: OUT[8x16][4C], two passes of 128 channels =================
   const int wrow16 = (wn * 64 + (fr >> 2) * 16 + (fr & 3)) * ROWB;   // + 4i rows: 16 consecutive channels per lane
-#pragma unroll 1
+#pragma unroll
   for (int nc = 0; nc < 2; ++nc) {
-    const int ch0 = nc * 128 + wn * 64 + fq * 16;
-    // addend (and mask) of this lane's outputs: requested before the MFMAs, consumed after them
-    bf16x8_t ad[4][2], mk[4][2];
-    bool okp[4];
-    int64_t pixp[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int y = y0 + wm * 4 + j, x = x0 + fr;
-      okp[j] = (y < H) && (x < W);
-      pixp[j] = img_pix0 + (int64_t)y * W + x;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        ad[j][h] = okp[j] ? *(const bf16x8_t*)(p.a + pixp[j] * C4 + ch0 + h * 8) : bf16x8_t{};
-        if constexpr (BWD) mk[j][h] = (okp[j] && p.m3) ? *(const bf16x8_t*)(p.m3 + pixp[j] * C4 + ch0 + h * 8) : bf16x8_t{};
-      }
-    }
+    const int ch0 = nc * 128 + chw;
     f32x4_t acc3[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc3[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const char* sW = smem + W3_OFF + nc * 128 * ROWB + wrow16;
-    const char* sX = smem + (wm * 64 + fr) * ROWB;
+    const char* sX = smem + H2_OFF + (wm * 64 + fr) * ROWB;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8_t wf[4], xf[4];
@@ -343,18 +394,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc3[i][j] = mfma16<F16>(wf[i], xf[j], acc3[i][j]);
     }
-    f32x4_t sc[4], sh[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      sc[i] = p.sc3 ? *(const f32x4_t*)(p.sc3 + ch0 + 4 * i) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
-      sh[i] = p.sh3 ? *(const f32x4_t*)(p.sh3 + ch0 + 4 * i) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
+    bf16x8_t ov[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (!okp[j]) continue;
       f32x4_t v[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = acc3[i][j] * sc[i] + sh[i];
+      for (int i = 0; i < 4; ++i) v[i] = acc3[i][j] * sc3v[i] + sh3v[i];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -368,8 +413,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
           for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              v[2 * h][e] = (elem_to_f32<F16>(mk[j][h][e]) > 0.f) ? v[2 * h][e] : 0.f;
-              v[2 * h + 1][e] = (elem_to_f32<F16>(mk[j][h][4 + e]) > 0.f) ? v[2 * h + 1][e] : 0.f;
+              v[2 * h][e] = (elem_to_f32<F16>(mk3[j][h][e]) > 0.f) ? v[2 * h][e] : 0.f;
+              v[2 * h + 1][e] = (elem_to_f32<F16>(mk3[j][h][4 + e]) > 0.f) ? v[2 * h + 1][e] : 0.f;
             }
         }
       } else {
@@ -379,15 +424,28 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
           for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        bf16x8_t o;
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          o[e] = f32_to_elem<F16>(v[2 * h][e]);
-          o[4 + e] = f32_to_elem<F16>(v[2 * h + 1][e]);
+          ov[j][h][e] = f32_to_elem<F16>(v[2 * h][e]);
+          ov[j][h][4 + e] = f32_to_elem<F16>(v[2 * h + 1][e]);
         }
-        *(bf16x8_t*)(p.o3 + pixp[j] * C4 + ch0 + h * 8) = o;
+    }
+    if (nc == 0) {   // the second pass's operands travel while the first pass's results are stored
+      load_addend(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, 128 + chw + 4 * i, sc3v[i], sh3v[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {   // h2 / g1 to HBM: behind every load a later wait counts
+        const int y = y0 + wm * 4 + j, x = x0 + pi;
+        if (y < H && x < W) *(bf16x8_t*)(p.o2 + (img_pix0 + (int64_t)y * W + x) * C + cb8) = o2v[j];
       }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!okp[j]) continue;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) *(bf16x8_t*)(p.o3 + pixp[j] * C4 + ch0 + h * 8) = ov[j][h];
     }
   }
 }
