@@ -15,7 +15,8 @@ os.environ["TDN_HALO"] = "0"
 from torch_detection_amd import ops  # noqa: E402
 from test_gpu_block import _case  # noqa: E402
 
-N, H, W, C = int(os.environ.get("N", 1)), 200, 336, 64
+C = int(os.environ.get("C", 64))
+N, H, W = int(os.environ.get("N", 1)), (200 if C == 64 else 100), (336 if C == 64 else 168)
 dt = torch.bfloat16
 dev = torch.device("cuda")
 x, w1, w2, w3, aff = _case(N, H, W, C, dt, 4242)

@@ -78,10 +78,10 @@ def _fwd_ref(x, w1, w2, w3, aff, dtype):
 SHAPES = [(1, 8, 16), (1, 16, 32), (2, 24, 48), (1, 13, 21), (3, 5, 7), (1, 17, 40), (2, 9, 33)]
 
 
+@pytest.mark.parametrize("C", [64, 128])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,W", SHAPES)
-def test_block_forward(ops, generic_tiles, N, H, W, dtype):
-    C = 64
+def test_block_forward(ops, generic_tiles, N, H, W, dtype, C):
     if not ops.bottleneck_supported(H, W, C):
         pytest.skip("no one-launch kernel for C=%d in this build" % C)
     x, w1, w2, w3, aff = _case(N, H, W, C, dtype, 100 * H + W)
@@ -107,11 +107,11 @@ def test_block_forward(ops, generic_tiles, N, H, W, dtype):
         assert err <= (TOL + ulp) * b.abs().max().item() + 1e-6, (name, err, b.abs().max().item())
 
 
+@pytest.mark.parametrize("C", [64, 128])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,W", SHAPES)
 @pytest.mark.parametrize("with_mask3", [True, False])
-def test_block_dgrad(ops, generic_tiles, N, H, W, dtype, with_mask3):
-    C = 64
+def test_block_dgrad(ops, generic_tiles, N, H, W, dtype, with_mask3, C):
     if not ops.bottleneck_supported(H, W, C):
         pytest.skip("no one-launch kernel for C=%d in this build" % C)
     C4 = 4 * C
@@ -155,9 +155,12 @@ def test_block_dgrad(ops, generic_tiles, N, H, W, dtype, with_mask3):
 
 
 @pytest.mark.parametrize("rep", range(3))
-def test_block_layer1_geometry(ops, generic_tiles, rep):
-    """BASELINE geometry of layer1 (one image, 200 x 336, 64 mid channels): bit for bit against the per-conv path."""
-    N, H, W, C, dtype = 1, 200, 336, 64, torch.bfloat16
+@pytest.mark.parametrize("H,W,C", [(200, 336, 64), (100, 168, 128)])
+def test_block_baseline_geometry(ops, generic_tiles, rep, H, W, C):
+    """BASELINE geometry of layer1 / layer2 (one image, 200 x 336 x 64 / 100 x 168 x 128 mid channels): bit for bit
+    against the per-conv path, forward and backward; repeated, because a hazard between workgroup phases only shows
+    with every CU busy (scripts/block_race.py)."""
+    N, dtype = 1, torch.bfloat16
     x, w1, w2, w3, aff = _case(N, H, W, C, dtype, 4242)
     dev = torch.device("cuda")
     xg, w1g, w2g, w3g = (t.contiguous().to(dev) for t in (x, w1, w2, w3))
@@ -167,7 +170,15 @@ def test_block_layer1_geometry(ops, generic_tiles, rep):
     r2 = ops.conv2d_fwd(r1, w2g, 3, 1, 1, affg[2], affg[3], relu=True)
     r3 = ops.conv2d_fwd(r2, w3g, 1, 1, 0, affg[4], affg[5], xg, ops.ADD_SAME, True)
     torch.cuda.synchronize()
-    for name, a, b in (("h1", h1, r1), ("h2", h2, r2), ("out", out, r3)):
+    w1d, w2d, w3d = (w.permute(3, 1, 2, 0).contiguous() for w in (w1g, w2g, w3g))
+    g = torch.where(out > 0, (det_tensor((N, H, W, 4 * C), 777) * 0.1).to(dtype).to(dev), torch.zeros((), device=dev, dtype=dtype))
+    g = g.contiguous()
+    g2, g1, dx = ops.bottleneck_dgrad(g, w3d, w2d, w1d, (h2, h1, xg))
+    q2 = ops.conv2d_dgrad(g, w3d, (H, W), 1, 1, 0, mask_src=h2)
+    q1 = ops.conv2d_dgrad(q2, w2d, (H, W), 3, 1, 1, mask_src=h1)
+    qx = ops.conv2d_dgrad(q1, w1d, (H, W), 1, 1, 0, g, ops.ADD_SAME, xg)
+    torch.cuda.synchronize()
+    for name, a, b in (("h1", h1, r1), ("h2", h2, r2), ("out", out, r3), ("g2", g2, q2), ("g1", g1, q1), ("dx", dx, qx)):
         ne = (a.view(torch.int16) != b.view(torch.int16))
         if bool(ne.any()):
             idx = ne.nonzero()[:8].tolist()

@@ -34,6 +34,7 @@
 // width: a fragment never straddles two patch rows, cf. the halo kernel's residual conflicts).
 #include "common.h"
 #include <string.h>
+#include <type_traits>
 
 struct BlockParams {
   const bf16_t* a;     // [N][H][W][4C]   forward: x; backward: g
@@ -51,7 +52,28 @@ struct BlockParams {
   bf16_t* o3;          // [N][H][W][4C]   out / dx
   int N, H, W;
   int tiles_x, tiles_y, ntiles, nwg_pad;
+  unsigned long long* trace;   // libtdn_trace.so only: 16 x 8-byte stamps per workgroup (scripts/block_trace.py)
 };
+
+#ifdef TDN_TRACE_BUILD
+#define BLK_STAMP(slot)                                                                                   \
+  do {                                                                                                    \
+    if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter();   \
+  } while (0)
+#define BLK_STAMP_RT(slot)                                                                                \
+  do {                                                                                                    \
+    if (p.trace && tid == 0) p.trace[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define BLK_STAMP(slot) do { } while (0)
+#define BLK_STAMP_RT(slot) do { } while (0)
+#endif
+
+// Store target of output pixels that lie outside the image (ragged right / bottom tiles): the epilogue's loads and
+// stores are then unconditional — address selects, no branches — so the compiler can count what is in flight behind a
+// load instead of waiting vmcnt(0), which would drain the stores issued before it.
+static __device__ __attribute__((aligned(256))) unsigned char g_blk_sink[512];
+static __device__ __attribute__((aligned(256))) unsigned char g_blk_zero[512];   // load source of such pixels (a lane reads up to 288 B behind its base)
 
 // Workgroup barrier that is also a compiler barrier for memory operations and retires this wave's LDS reads first.
 // The raw __builtin_amdgcn_s_barrier() orders nothing for the compiler: a ds_write into a region other waves were
@@ -84,6 +106,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   const int bid = blockIdx.x;
   const int tile = (bid & 7) * (p.nwg_pad >> 3) + (bid >> 3);   // XCD x owns a contiguous run of tiles (shared halos)
   if (tile >= p.ntiles) return;
+  BLK_STAMP(0);
+  BLK_STAMP_RT(14);
   const int H = p.H, W = p.W;
   const int tpi = p.tiles_x * p.tiles_y;
   const int img = tile / tpi;
@@ -188,6 +212,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     // the barrier; a read still queued in the LDS pipe can then be overtaken by the LDS-DMA another wave issues into
     // the same ring slot right behind the barrier (seen: 1 KiB pieces of stale data in ~10 of 525 tiles per launch)
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // K-step kc landed; slot (kc - 1) & 3 is free
+    if (kc == 0) BLK_STAMP(1);
+    if (kc == 4) BLK_STAMP(2);
     if (kc + 3 < 8) load_step(kc + 3);
     else if (kc == 5) { load_tap(2); load_tap(3); }
     else if (kc == 6) { load_tap(4); load_tap(5); }
@@ -205,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       for (int j = 0; j < 6; ++j) acc1[i][j] = mfma16<F16>(wf[i], xf[j], acc1[i][j]);
   }
   lds_barrier();   // b0: every wave is done reading the ring
+  BLK_STAMP(3);
 
   bf16x8_t o1v[6];
   unsigned st1 = 0;               // bit j: fragment j of this lane is an interior pixel inside the image -> stored
@@ -245,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   }
   // b1: H1 complete (LDS writes of every wave), taps 2..6 landed (taps 0 / 1 long ago)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  BLK_STAMP(4);
   // h1 / g2 to HBM: behind the barrier, so that nobody waits for the stores
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -293,11 +321,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   tap_compute(0);
   tap_compute(1);
   lds_barrier();   // b2: [65536, 81920) is free
+  BLK_STAMP(5);
   load_tap(7);
   load_tap(8);
 #pragma unroll
   for (int t = 2; t < 7; ++t) tap_compute(t);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // b3: taps 7, 8 landed; [0, 40960) is free
+  BLK_STAMP(6);
   // conv3 weights [4C][C] into [0, 32768) while taps 7 and 8 are multiplied
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
@@ -307,13 +337,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   }
   // addend (and mask) of the first 128 output channels: requested now, consumed after phase 3's first pass
   const int chw = wn * 64 + fq * 16;       // + nc * 128: this lane's 16 consecutive output channels
-  bool okp[4];
-  int64_t pixp[4];
+  // Loads and stores of output pixels outside the image (ragged tiles) are redirected to the zero page / a sink line
+  // instead of being branched around: see g_blk_sink.
+  const bf16_t* adp[4];
+  const bf16_t* mkp[4];
+  bf16_t* o3p[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int y = y0 + wm * 4 + j, x = x0 + fr;
-    okp[j] = (y < H) && (x < W);
-    pixp[j] = img_pix0 + (int64_t)y * W + x;
+    const bool ok = (y < H) && (x < W);
+    const int64_t off = (img_pix0 + (int64_t)y * W + x) * C4 + chw;
+    adp[j] = ok ? p.a + off : (const bf16_t*)g_blk_zero;
+    mkp[j] = (ok && p.m3) ? p.m3 + off : (const bf16_t*)g_blk_zero;
+    o3p[j] = ok ? p.o3 + off : (bf16_t*)g_blk_sink;
   }
   bf16x8_t ad[4][2], mk3[4][2];
   auto load_addend = [&](int nc) {
@@ -321,9 +357,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        ad[j][h] = okp[j] ? *(const bf16x8_t*)(p.a + pixp[j] * C4 + nc * 128 + chw + h * 8) : bf16x8_t{};
-        if constexpr (BWD)
-          mk3[j][h] = (okp[j] && p.m3) ? *(const bf16x8_t*)(p.m3 + pixp[j] * C4 + nc * 128 + chw + h * 8) : bf16x8_t{};
+        ad[j][h] = *(const bf16x8_t*)(adp[j] + nc * 128 + h * 8);
+        if constexpr (BWD) mk3[j][h] = *(const bf16x8_t*)(mkp[j] + nc * 128 + h * 8);
       }
   };
   load_addend(0);
@@ -333,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   tap_compute(7);
   tap_compute(8);
   lds_barrier();   // b4: every wave is done with H1
+  BLK_STAMP(7);
   bf16x8_t o2v[4];
   f32x4_t sc3v[4], sh3v[4];
   {
@@ -370,29 +406,463 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, chw + 4 * i, sc3v[i], sh3v[i]);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // b5: H2 complete, conv3 weights landed
 
+  BLK_STAMP(8);
   // ================= phase 3: OUT[8x16][4C], two passes of 128 channels =================
   const int wrow16 = (wn * 64 + (fr >> 2) * 16 + (fr & 3)) * ROWB;   // + 4i rows: 16 consecutive channels per lane
+  {
+#pragma unroll
+    for (int nc = 0; nc < 2; ++nc) {
+      __builtin_amdgcn_sched_barrier(0);   // keep the passes apart: hoisting the second one's loads and MFMAs spills
+      f32x4_t acc3[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc3[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const char* sW = smem + W3_OFF + nc * 128 * ROWB + wrow16;
+      const char* sX = smem + H2_OFF + (wm * 64 + fr) * ROWB;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8_t wf[4], xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = lds_read_b128(sW + i * 4 * ROWB + (((kk * 4 + fq) ^ f_rd_w) * 16));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[j] = lds_read_b128(sX + j * 16 * ROWB + (((kk * 4 + fq) ^ f_rd) * 16));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc3[i][j] = mfma16<F16>(wf[i], xf[j], acc3[i][j]);
+      }
+      bf16x8_t ov[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc3[i][j] * sc3v[i] + sh3v[i];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * h][e] += elem_to_f32<F16>(ad[j][h][e]);
+            v[2 * h + 1][e] += elem_to_f32<F16>(ad[j][h][4 + e]);
+          }
+        if constexpr (BWD) {
+          const bool has_m3 = p.m3 != nullptr;   // no mask: the select below keeps every value
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * h][e] = (!has_m3 || elem_to_f32<F16>(mk3[j][h][e]) > 0.f) ? v[2 * h][e] : 0.f;
+              v[2 * h + 1][e] = (!has_m3 || elem_to_f32<F16>(mk3[j][h][4 + e]) > 0.f) ? v[2 * h + 1][e] : 0.f;
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ov[j][h][e] = f32_to_elem<F16>(v[2 * h][e]);
+            ov[j][h][4 + e] = f32_to_elem<F16>(v[2 * h + 1][e]);
+          }
+      }
+      BLK_STAMP(9 + nc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (nc == 0) {   // the second pass's operands travel while the first pass's results are stored
+        load_addend(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, 128 + chw + 4 * i, sc3v[i], sh3v[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // h2 / g1 to HBM: behind every load a later wait counts
+          const int y = y0 + wm * 4 + j, x = x0 + pi;
+          bf16_t* dst = (y < H && x < W) ? p.o2 + (img_pix0 + (int64_t)y * W + x) * C + cb8 : (bf16_t*)g_blk_sink;
+          *(bf16x8_t*)dst = o2v[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *(bf16x8_t*)(o3p[j] + nc * 128 + h * 8) = ov[j][h];
+    }
+  }
+#ifdef TDN_TRACE_BUILD
+  BLK_STAMP(11);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BLK_STAMP(12);
+  BLK_STAMP_RT(15);
+  if (p.trace && tid == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.trace[(size_t)blockIdx.x * 16 + 13] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// C = 128 (layer2): the same three phases with 8 waves (2 pixel halves x 4 channel quarters, the per-wave tiles of
+// the C = 64 kernel), one workgroup per CU and all 160 KB of LDS:
+//   [0, 49152)        H1[192 rows][256 B]   (later H2[128 rows][256 B])
+//   [49152, 163840)   seven 16 KB slots.  Phase 1 lays its four 20 KB K-step slots (X 12 KB + W1 8 KB per 32 channels)
+//                     over the first five; everything else is a stream of 26 weight UNITS of 128 rows x 64 K-values
+//                     (16 KB, two LDS-DMA instructions per wave) through the seven slots, unit u in slot (u + 5) % 7:
+//                       u = 0..17   conv2, half h = u / 9 of the input channels, tap t = u % 9
+//                                   (channel chunk outer, taps inner: the K order of conv_gemm_kernel / conv_halo_kernel)
+//                       u = 18..25  conv3, pass nc = (u - 18) / 4, row half (u - 18) / 2 % 2, K half (u - 18) % 2
+//                     Units 0, 1 are issued at kernel start, 2..4 into the K-step slots phase 1 releases, then one unit
+//                     per consumed unit: six units stay in flight (counted vmcnt).
+// 256-byte rows: chunk swizzle f(R) = 2 * ((R >> 1) & 7); with the even / odd pixel deal (also used by phase 3 here)
+// the eight lanes of a ds_read_b128 lane group that share a k-chunk see eight consecutive values of R >> 1, and the
+// two k-chunks of a group differ in bit 0, which f leaves alone.
+// ---------------------------------------------------------------------------------------------
+template <bool BWD, bool F16>
+__global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int C = 128, C4 = 512, TH = 8, TW = 16, HWD = TW + 2, PH = (TH + 2) * HWD /* 180 */, PHP = 192;
+  constexpr int RB = 256;                      // H1 / H2 row bytes
+  constexpr int WRB = 128;                     // weight unit row bytes
+  constexpr int RING = 49152, UB = 16384;      // unit slot s: RING + s * UB
+  constexpr int P1SLOT = 20480, XB32 = PHP * 64;   // phase 1 K-step slot s: RING + s * P1SLOT
+  constexpr int KS1 = C4 / 32;                 // 16 K-steps of 32 channels
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int bid = blockIdx.x;
+  const int tile = (bid & 7) * (p.nwg_pad >> 3) + (bid >> 3);
+  if (tile >= p.ntiles) return;
+  BLK_STAMP(0);
+  BLK_STAMP_RT(14);
+  const int H = p.H, W = p.W;
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int img = tile / tpi;
+  const int trem = tile - img * tpi;
+  const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int64_t img_pix0 = (int64_t)img * H * W;
+
+  auto swz_w8 = [](int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); };
+  auto swz_w16 = [](int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); };
+  auto f256 = [](int R) { return ((R >> 1) & 7) << 1; };
+
+  // ---- weight units ----
+  const int lrow8 = lane >> 3, lchunk8 = lane & 7;
+  auto unit_off = [](int u) { return RING + ((u + 5) % 7) * UB; };
+  auto load_unit = [&](int u) {
+    char* dst = smem + unit_off(u);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int g8 = it * 8 + wave;
+      const int r = g8 * 8 + lrow8;                  // row of the unit
+      const char* src;
+      if (u < 18) {
+        const int h = u / 9, t = u - h * 9;
+        src = (const char*)p.w2 + ((int64_t)r * (9 * C) + t * C + h * 64) * 2 + ((lchunk8 ^ swz_w8(r)) * 16);
+      } else {
+        const int v = u - 18, nc = v >> 2, ru = (v >> 1) & 1, h = v & 1;
+        src = (const char*)p.w3 + ((int64_t)(nc * 256 + ru * 128 + r) * C + h * 64) * 2 + ((lchunk8 ^ swz_w16(r)) * 16);
+      }
+      glds16_async(src, dst + g8 * 8 * WRB);
+    }
+  };
+  load_unit(0);
+  load_unit(1);
+
+  // ---- phase 1 loader: per K-step 12 X pieces (16 rows x 64 B) + 8 W1 pieces over 8 waves: every wave issues three
+  // LDS-DMA instructions (waves 4..7 have no second X piece: a dummy copy of the zero page into the idle H1 region
+  // keeps the per-wave vmcnt arithmetic uniform) ----
+  const int lrow16 = lane >> 2, lchunk4 = lane & 3;
+  const char* zero = (const char*)g_zero_page + lchunk4 * 16;
+  const char* xsrc[2];
+  unsigned xok = 0;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int R = (it * 8 + wave) * 16 + lrow16;
+    const int hy = R / HWD, hx = R - hy * HWD;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
+    const int swz = (4 - ((R >> 2) & 3)) & 3;
+    xsrc[it] = (const char*)p.a + ((img_pix0 + (int64_t)y * W + x) * C4 + ((lchunk4 ^ swz) * 8)) * 2;
+    xok |= ok ? (1u << it) : 0u;
+  }
+  const char* w1src;
+  {
+    const int n = wave * 16 + lrow16;
+    w1src = (const char*)p.w1 + ((int64_t)n * C4) * 2 + ((lchunk4 ^ ((4 - ((n >> 3) & 3)) & 3)) * 16);
+  }
+  auto load_step = [&](int kc) {
+    char* sX = smem + RING + (kc & 3) * P1SLOT;
+    glds16_async(xok & 1u ? xsrc[0] + kc * 64 : zero, sX + wave * 1024);
+    if (wave < 4) glds16_async(xok & 2u ? xsrc[1] + kc * 64 : zero, sX + (8 + wave) * 1024);
+    else glds16_async(zero, smem + wave * 1024);            // dummy, into the idle H1 region
+    glds16_async(w1src + kc * 64, sX + XB32 + wave * 1024);
+  };
+
+  const int f_rd_w = ((fr & 3) >> 1) | ((fr >> 2) << 1);
+  const int f_rd32 = (4 - (fr >> 2)) & 3;
+  const int wrow8 = wn * 32 + (fr >> 2) * 8 + (fr & 3);
+  const int pi = fr < 4 ? 2 * fr : (fr >= 12 ? 2 * (fr - 8) : 2 * (fr - 4) + 1);
+  const int cb8 = wn * 32 + fq * 8;
+
+  auto load_affine = [&](const float* scp, const float* shp, int ch, f32x4_t& sc, f32x4_t& sh) {
+    sc = (!BWD && scp) ? *(const f32x4_t*)(scp + ch) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+    sh = (!BWD && shp) ? *(const f32x4_t*)(shp + ch) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
+  f32x4_t sc1v[2], sh1v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) load_affine(p.sc1, p.sh1, cb8 + 4 * i, sc1v[i], sh1v[i]);
+  bf16x8_t mk1[6];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int R = wm * 96 + j * 16 + fr;
+      const int hy = R / HWD, hx = R - hy * HWD;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
+      mk1[j] = *(const bf16x8_t*)((ok && p.m1) ? p.m1 + (img_pix0 + (int64_t)y * W + x) * C + cb8 : (const bf16_t*)g_blk_zero);
+    }
+  }
+
+  // ================= phase 1 =================
+  f32x4_t acc1[2][6];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc1[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  load_step(0);
+  load_step(1);
+  load_step(2);
+#pragma unroll
+  for (int kc = 0; kc < KS1; ++kc) {
+    // younger than K-step kc at this point: two K-steps (3 LDS-DMA each), or the units that take their place at the tail
+    if (kc <= KS1 - 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (kc == KS1 - 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kc == 0) BLK_STAMP(1);
+    if (kc == 8) BLK_STAMP(2);
+    if (kc + 3 < KS1) load_step(kc + 3);
+    else load_unit(kc + 3 - KS1 + 2);            // kc = 13, 14, 15 -> units 2, 3, 4 into the slots just released
+    const char* sX = smem + RING + (kc & 3) * P1SLOT + (wm * 96 + fr) * 64 + ((fq ^ f_rd32) * 16);
+    const char* sW = smem + RING + (kc & 3) * P1SLOT + XB32 + wrow8 * 64 + ((fq ^ f_rd32) * 16);
+    bf16x8_t wf[2], xf[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wf[i] = lds_read_b128(sW + i * 4 * 64);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) xf[j] = lds_read_b128(sX + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc1[i][j] = mfma16<F16>(wf[i], xf[j], acc1[i][j]);
+  }
+  lds_barrier();   // b0: the K-step slots are free
+  BLK_STAMP(3);
+  // Compiler-visible loads / stores share the vmcnt queue with the LDS-DMA stream.  They are placed where the counted
+  // waits of the unit stream only ever find them OLDER than the units they may leave in flight (a count that is too
+  // small over-waits; one that is too large would let a unit be read before it has landed): the phase 2 mask loads and
+  // the h1 / g2 stores go in front of units 5 and 6.
+  bf16x8_t mk2[4];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + wm * 4 + j, x = x0 + pi;
+      mk2[j] = *(const bf16x8_t*)((p.m2 && y < H && x < W) ? p.m2 + (img_pix0 + (int64_t)y * W + x) * C + cb8
+                                                             : (const bf16_t*)g_blk_zero);
+    }
+  }
+
+  bf16x8_t o1v[6];
+  unsigned st1 = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int R = wm * 96 + j * 16 + fr;
+    const int hy = R / HWD, hx = R - hy * HWD;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
+    f32x4_t v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] = acc1[i][j] * sc1v[i] + sh1v[i];
+    if constexpr (BWD) {
+      if (p.m1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[0][e] = (elem_to_f32<F16>(mk1[j][e]) > 0.f) ? v[0][e] : 0.f;
+          v[1][e] = (elem_to_f32<F16>(mk1[j][4 + e]) > 0.f) ? v[1][e] : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
+    }
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = f32_to_elem<F16>(ok ? v[0][e] : 0.f);
+      o[4 + e] = f32_to_elem<F16>(ok ? v[1][e] : 0.f);
+    }
+    *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + R * RB + (((wn * 4 + fq) ^ f256(R)) * 16)) = o;
+    o1v[j] = o;
+    st1 |= (ok && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW) ? (1u << j) : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {   // h1 / g2 to HBM
+    if ((st1 >> j) & 1u) {
+      const int R = wm * 96 + j * 16 + fr;
+      const int hy = R / HWD, hx = R - hy * HWD;
+      *(bf16x8_t*)(p.o1 + (img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx)) * C + cb8) = o1v[j];
+    }
+  }
+  load_unit(5);
+  load_unit(6);
+
+  // ================= phase 2: 18 units =================
+  f32x4_t acc2[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // phase 3 operand addresses (dealt pixel pi of tile row wm * 4 + j)
+  const int chw = wn * 64 + fq * 16;       // + nc * 256
+  const bf16_t* adp[4];
+  const bf16_t* mkp[4];
+  bf16_t* o3p[4];
+  bf16_t* o2p[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int y = y0 + wm * 4 + j, x = x0 + pi;
+    const bool ok = (y < H) && (x < W);
+    const int64_t pix = img_pix0 + (int64_t)y * W + x;
+    adp[j] = ok ? p.a + pix * C4 + chw : (const bf16_t*)g_blk_zero;
+    mkp[j] = (ok && p.m3) ? p.m3 + pix * C4 + chw : (const bf16_t*)g_blk_zero;
+    o3p[j] = ok ? p.o3 + pix * C4 + chw : (bf16_t*)g_blk_sink;
+    o2p[j] = ok ? p.o2 + pix * C + cb8 : (bf16_t*)g_blk_sink;
+  }
+#pragma unroll
+  for (int u = 0; u < 18; ++u) {
+    // unit u landed for every wave; the slot of unit u - 1 is free.  In flight behind it: units u + 1 .. u + 5
+    // (u = 0: .. u + 6), two LDS-DMA instructions each
+    if (u == 0) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // + H1 complete
+    else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (u >= 1) load_unit(u + 6);
+    if (u == 0) BLK_STAMP(4);
+    if (u == 9) BLK_STAMP(5);
+    const int h = u / 9, t = u - h * 9;
+    const int ky = t / 3, kx = t - ky * 3;
+    const int oy = BWD ? 2 - ky : ky, ox = BWD ? 2 - kx : kx;
+    const char* sW = smem + unit_off(u) + wrow8 * WRB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t wf[2], xf[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[i] = lds_read_b128(sW + i * 4 * WRB + (((kk * 4 + fq) ^ f_rd_w) * 16));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int R = (wm * 4 + j + oy) * HWD + pi + ox;
+        xf[j] = lds_read_b128(smem + R * RB + (((h * 8 + kk * 4 + fq) ^ f256(R)) * 16));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[i][j] = mfma16<F16>(wf[i], xf[j], acc2[i][j]);
+    }
+  }
+  lds_barrier();   // b4: H1 is dead; the slot of unit 17 is free
+  BLK_STAMP(6);
+  // first pass's addend / mask / affine: in front of unit 24, so that b5's counted wait covers them
+  bf16x8_t ad[4][2], mk3[4][2];
+  auto load_addend = [&](int nc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ad[j][h] = *(const bf16x8_t*)(adp[j] + nc * 256 + h * 8);
+        if constexpr (BWD) mk3[j][h] = *(const bf16x8_t*)(mkp[j] + nc * 256 + h * 8);
+      }
+  };
+  load_addend(0);
+  f32x4_t sc3v[4], sh3v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, chw + 4 * i, sc3v[i], sh3v[i]);
+  bf16x8_t o2v[4];
+  {
+    f32x4_t sc2v[2], sh2v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) load_affine(p.sc2, p.sh2, cb8 + 4 * i, sc2v[i], sh2v[i]);
+    asm volatile("" ::: "memory");   // the loads above stay in front of the unit below
+    load_unit(24);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4_t v[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = acc2[i][j] * sc2v[i] + sh2v[i];
+      if constexpr (BWD) {
+        if (p.m2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[0][e] = (elem_to_f32<F16>(mk2[j][e]) > 0.f) ? v[0][e] : 0.f;
+            v[1][e] = (elem_to_f32<F16>(mk2[j][4 + e]) > 0.f) ? v[1][e] : 0.f;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
+      }
+      bf16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = f32_to_elem<F16>(v[0][e]);
+        o[4 + e] = f32_to_elem<F16>(v[1][e]);
+      }
+      const int pr = (wm * 4 + j) * TW + pi;
+      *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + pr * RB + (((wn * 4 + fq) ^ f256(pr)) * 16)) = o;
+      o2v[j] = o;
+    }
+  }
+  // b5: H2 complete; conv3 units 18..21 landed (22..24 may still travel; compiler-visible loads in between only make
+  // the counted wait stricter)
+  asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  BLK_STAMP(8);
+
+  // ================= phase 3: two passes of 256 channels =================
+  const int lrow3 = ((wn & 1) * 64 + (fr >> 2) * 16 + (fr & 3)) * WRB;   // + 4i rows, inside row-half unit wn >> 1
 #pragma unroll
   for (int nc = 0; nc < 2; ++nc) {
-    const int ch0 = nc * 128 + chw;
+    __builtin_amdgcn_sched_barrier(0);
     f32x4_t acc3[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc3[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const char* sW = smem + W3_OFF + nc * 128 * ROWB + wrow16;
-    const char* sX = smem + H2_OFF + (wm * 64 + fr) * ROWB;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t wf[4], xf[4];
+    for (int h = 0; h < 2; ++h) {
+      const char* sW = smem + unit_off(18 + nc * 4 + (wn >> 1) * 2 + h) + lrow3;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = lds_read_b128(sW + i * 4 * ROWB + (((kk * 4 + fq) ^ f_rd_w) * 16));
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8_t wf[4], xf[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xf[j] = lds_read_b128(sX + j * 16 * ROWB + (((kk * 4 + fq) ^ f_rd) * 16));
+        for (int i = 0; i < 4; ++i) wf[i] = lds_read_b128(sW + i * 4 * WRB + (((kk * 4 + fq) ^ f_rd_w) * 16));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          const int pr = (wm * 4 + j) * TW + pi;
+          xf[j] = lds_read_b128(smem + pr * RB + (((h * 8 + kk * 4 + fq) ^ f256(pr)) * 16));
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc3[i][j] = mfma16<F16>(wf[i], xf[j], acc3[i][j]);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc3[i][j] = mfma16<F16>(wf[i], xf[j], acc3[i][j]);
+      }
+    }
+    if (nc == 0) {
+      lds_barrier();     // b6: every wave is done with units 18..21
+      load_unit(25);     // into the slot of unit 18
     }
     bf16x8_t ov[4][2];
 #pragma unroll
@@ -408,15 +878,14 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
           v[2 * h + 1][e] += elem_to_f32<F16>(ad[j][h][4 + e]);
         }
       if constexpr (BWD) {
-        if (p.m3) {
+        const bool has_m3 = p.m3 != nullptr;
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[2 * h][e] = (elem_to_f32<F16>(mk3[j][h][e]) > 0.f) ? v[2 * h][e] : 0.f;
-              v[2 * h + 1][e] = (elem_to_f32<F16>(mk3[j][h][4 + e]) > 0.f) ? v[2 * h + 1][e] : 0.f;
-            }
-        }
+          for (int e = 0; e < 4; ++e) {
+            v[2 * h][e] = (!has_m3 || elem_to_f32<F16>(mk3[j][h][e]) > 0.f) ? v[2 * h][e] : 0.f;
+            v[2 * h + 1][e] = (!has_m3 || elem_to_f32<F16>(mk3[j][h][4 + e]) > 0.f) ? v[2 * h + 1][e] : 0.f;
+          }
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -431,23 +900,29 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
           ov[j][h][4 + e] = f32_to_elem<F16>(v[2 * h + 1][e]);
         }
     }
-    if (nc == 0) {   // the second pass's operands travel while the first pass's results are stored
+    BLK_STAMP(9 + nc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nc == 0) {
       load_addend(1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, 128 + chw + 4 * i, sc3v[i], sh3v[i]);
+      for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, 256 + chw + 4 * i, sc3v[i], sh3v[i]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {   // h2 / g1 to HBM: behind every load a later wait counts
-        const int y = y0 + wm * 4 + j, x = x0 + pi;
-        if (y < H && x < W) *(bf16x8_t*)(p.o2 + (img_pix0 + (int64_t)y * W + x) * C + cb8) = o2v[j];
-      }
+      for (int j = 0; j < 4; ++j) *(bf16x8_t*)o2p[j] = o2v[j];     // h2 / g1
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (!okp[j]) continue;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) *(bf16x8_t*)(p.o3 + pixp[j] * C4 + ch0 + h * 8) = ov[j][h];
-    }
+      for (int h = 0; h < 2; ++h) *(bf16x8_t*)(o3p[j] + nc * 256 + h * 8) = ov[j][h];
+    // b7: units 22..25 landed.  Behind unit 25 this wave has issued 8 addend loads (+ 8 mask loads, or up to 8 affine
+    // loads), 4 + 8 stores — all unconditional (sink / zero-page redirect): at least 20 younger operations
+    if (nc == 0) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+#ifdef TDN_TRACE_BUILD
+  BLK_STAMP(11);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BLK_STAMP(12);
+  BLK_STAMP_RT(15);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -475,15 +950,37 @@ static int launch_block64(BlockParams& p, hipStream_t stream) {
   return 0;
 }
 
+#ifdef TDN_TRACE_BUILD
+static unsigned long long* g_blk_trace = nullptr;
+extern "C" int tdn_debug_block_trace(void* buf) { g_blk_trace = (unsigned long long*)buf; return 0; }   // >= 128 B per workgroup
+#endif
+
+template <bool BWD, bool F16>
+static int launch_block128(BlockParams& p, hipStream_t stream) {
+  constexpr int lds = 163840;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)bottleneck128_kernel<BWD, F16>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
+    attr_set[dev] = true;
+  }
+  TDN_LAUNCH((bottleneck128_kernel<BWD, F16>), dim3(p.nwg_pad), dim3(512), lds, stream, p);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int tdn_bottleneck_supported(int H, int W, int C, int stride, int dilation) {
-  return (C == 64 && stride == 1 && dilation == 1 && H > 0 && W > 0) ? 1 : 0;
+  return ((C == 64 || C == 128) && stride == 1 && dilation == 1 && H > 0 && W > 0) ? 1 : 0;
 }
 
 static int block_common(BlockParams& p, const tdn_bottleneck_args* a, int dtype) {
   TDN_CHECK_DTYPE(dtype);
   TDN_CHECK(a != nullptr, "bottleneck: NULL argument block");
   TDN_CHECK(a->N > 0 && a->H > 0 && a->W > 0, "bottleneck: bad tensor shape N=%d H=%d W=%d", a->N, a->H, a->W);
-  TDN_CHECK(tdn_bottleneck_supported(a->H, a->W, a->C, 1, 1), "bottleneck: C=%d is not built (64)", a->C);
+  TDN_CHECK(tdn_bottleneck_supported(a->H, a->W, a->C, 1, 1), "bottleneck: C=%d is not built (64, 128)", a->C);
   TDN_CHECK(a->in && a->w1 && a->w2 && a->w3 && a->out1 && a->out2 && a->out3, "bottleneck: NULL tensor pointer");
   TDN_CHECK((int64_t)a->N * a->H * a->W < (1ll << 31) / 4, "tensor too large for 32-bit pixel indexing");
   memset(&p, 0, sizeof(p));
@@ -493,6 +990,9 @@ static int block_common(BlockParams& p, const tdn_bottleneck_args* a, int dtype)
   p.tiles_x = ceil_div(a->W, 16); p.tiles_y = ceil_div(a->H, 8);
   p.ntiles = a->N * p.tiles_x * p.tiles_y;
   p.nwg_pad = (p.ntiles + 7) & ~7;
+#ifdef TDN_TRACE_BUILD
+  p.trace = g_blk_trace;
+#endif
   return 0;
 }
 
@@ -500,6 +1000,10 @@ extern "C" int tdn_bottleneck_fwd(const tdn_bottleneck_args* a, int dtype, void*
   BlockParams p;
   if (block_common(p, a, dtype)) return -1;
   p.sc1 = a->scale1; p.sh1 = a->shift1; p.sc2 = a->scale2; p.sh2 = a->shift2; p.sc3 = a->scale3; p.sh3 = a->shift3;
+  if (a->C == 128) {
+    if (dtype == TDN_F16) return launch_block128<false, true>(p, (hipStream_t)stream);
+    return launch_block128<false, false>(p, (hipStream_t)stream);
+  }
   if (dtype == TDN_F16) return launch_block64<false, true>(p, (hipStream_t)stream);
   return launch_block64<false, false>(p, (hipStream_t)stream);
 }
@@ -508,6 +1012,10 @@ extern "C" int tdn_bottleneck_dgrad(const tdn_bottleneck_args* a, int dtype, voi
   BlockParams p;
   if (block_common(p, a, dtype)) return -1;
   p.m1 = (const bf16_t*)a->mask1; p.m2 = (const bf16_t*)a->mask2; p.m3 = (const bf16_t*)a->mask3;
+  if (a->C == 128) {
+    if (dtype == TDN_F16) return launch_block128<true, true>(p, (hipStream_t)stream);
+    return launch_block128<true, false>(p, (hipStream_t)stream);
+  }
   if (dtype == TDN_F16) return launch_block64<true, true>(p, (hipStream_t)stream);
   return launch_block64<true, false>(p, (hipStream_t)stream);
 }

@@ -817,7 +817,10 @@ def _block_fusable(b, C4):
     one-launch kernel for its width in this build (csrc/conv_block.hip): conv1 -> conv2 -> conv3 + residual run as
     ONE launch, forward (ops.bottleneck_fwd) and input-gradient chain (ops.bottleneck_dgrad).  TDN_BLOCK_FUSE=0
     keeps the per-conv launches (A/B runs, and the reference side of tests/test_gpu_block.py)."""
-    if b.kind != 'bottleneck' or b.ud is not None or b.stride != 1 or os.environ.get('TDN_BLOCK_FUSE', '1') == '0':
+    knob = os.environ.get('TDN_BLOCK_FUSE', '1')     # 0: off; 1: every width the build has; 64 / 128: up to that width
+    if b.kind != 'bottleneck' or b.ud is not None or b.stride != 1 or knob == '0':
+        return False
+    if knob not in ('', '1') and b.u1.Cout > int(knob):
         return False
     u1, u2, u3 = b.u1, b.u2, b.u3
     for u in (u1, u2, u3):
