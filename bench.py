@@ -121,8 +121,13 @@ def dominant_by_time():
     if not rows:
         return None
     fam = {}
-    for r in rows:     # pool the instantiations of one kernel template by tile shape (the first template arguments)
-        name = re.sub(r"^void ", "", r["Name"]).split("(")[0]
+    for r in rows:
+        # pool the instantiations of one kernel template by tile shape: kernel name + its first two template arguments
+        # (BM, BN of conv_gemm_kernel / FM, FN of conv_halo_kernel / BMW, BNW of the weight-gradient kernels), so that
+        # e.g. the plain, the K-group and the BK = 128 builds of the 64 x 64 tile count as one family
+        full = re.sub(r"^void ", "", r["Name"]).split("(")[0]
+        m = re.match(r"([A-Za-z0-9_]+)<\s*([^,>]+)\s*,\s*([^,>]+)", full)
+        name = "%s<%s, %s, ...>" % (m.group(1), m.group(2).strip(), m.group(3).strip()) if m else full
         fam[name] = fam.get(name, 0.0) + float(r["Percentage"])
     name, share = max(fam.items(), key=lambda kv: kv[1])
     out = {"symbol": name, "share": round(share / 100.0, 4), "source": os.path.relpath(files[-1], ROOT), "mfma_busy": None}
@@ -130,7 +135,8 @@ def dominant_by_time():
     for f in reversed(pmc):
         for b in re.split(r"\n\s*\n", open(f).read()):
             head = b.strip().split("\n")[0].strip()
-            if head and not head.startswith("#") and head.rstrip(".>") and name.startswith(head.rstrip(".>")):
+            stem = name.split(", ...>")[0]
+            if head and not head.startswith("#") and head.rstrip(".>") and head.startswith(stem):
                 m = re.search(r"MFMA pipe utilisation: ([0-9.]+)", b)
                 if m:
                     out["mfma_busy"] = float(m.group(1))
@@ -539,6 +545,10 @@ def main():
             # the same step with every conv's BN fold + weight pack re-run inside the graph (grouped launches), i.e.
             # what one iteration of a training loop pays on top once an optimizer changes the weights
             line["ms_per_step_with_repack"] = round(ms_repack, 3)
+            line["value_with_repack"] = round(B * world / (ms_repack * 1e-3), 2)
+        # what torch.distributed reported after init (1 = no process group): lets the driver's N-rank check read the
+        # world size the collectives actually ran over
+        line["rccl_world"] = dist.get_world_size() if (use_dist and dist.is_initialized()) else 1
         if world == 1 and not args.no_secondary:
             line["secondary"] = box_secondary(device)
         if world == 1 and not args.no_cpu_baseline:

@@ -340,7 +340,9 @@ int tdn_nhwc_to_nchw_f32(const void* src, int N, int C, int H, int W, float* dst
  *   tdn_plan_stream_wait(s, id) the host made stream s wait for that event here
  *   tdn_plan_end()              stop recording -> plan handle (NULL on error)
  *   tdn_plan_run(plan)          enqueue everything again, same streams, same order, same dependencies; no sync
- *   tdn_plan_stats(plan, out)   out[3] = {launches, event records, stream waits}
+ *   tdn_plan_stats(plan, out)   out[3] = {launches, event records, stream waits}; RETURNS the number of launches that were
+ *                               made by OTHER threads while the plan was being recorded and were therefore NOT kept
+ *                               (0 = the plan holds every launch of the recorded step; < 0: bad handle)
  *   tdn_plan_free(plan)
  * Pointers held by the recorded arguments must still refer to the same buffers when the plan runs (the host keeps the
  * recorded step's tensors alive in a private pool, like a captured graph does). */

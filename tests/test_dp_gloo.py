@@ -94,6 +94,20 @@ def test_two_rank_bf16_wire(tmp_path):
         assert rel_l2(r0[k], full[k] / world) <= 8e-3, k         # 2^-8 per rounding
 
 
+def test_three_rank_bf16_wire_average_is_scaled_in_fp32(tmp_path):
+    """A world size that is not a power of two: the 1 / world average of the 16-bit wire format must be taken in fp32
+    on the widened sum (one rounding), not in the 16-bit type (bf16 1.0 / 3 -> 0.33398 instead of 0.33333)."""
+    world = 3
+    mp.spawn(_worker, args=(world, _free_port(), 1 << 20, str(tmp_path), torch.bfloat16), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"), weights_only=True)
+    r2 = torch.load(os.path.join(str(tmp_path), "rank2.pt"), weights_only=True)
+    third = torch.tensor(1.0 / 3.0, dtype=torch.float32)
+    for k in r0:
+        assert torch.equal(r0[k], r2[k]), k
+        wire = (r0[k] * 3.0).bfloat16().float()          # the bf16 sum the wire carried
+        assert torch.equal(r0[k], wire * third), k       # == fp32(sum) * fp32(1 / 3), bit for bit
+
+
 def test_bf16_wire_halves_the_bucket_bytes():
     from torch_detection_amd import dp
     n = [1 << 18] * 8                                            # 8 MiB of fp32 gradients

@@ -119,3 +119,39 @@ def test_reducer_path_gradients_vs_cpu_oracle():
             assert res[kind][0] <= parity_util.BWD_IN_SITU_TOL, (kind, res[kind])
     finally:
         dist.destroy_process_group()
+
+
+def test_reducer_wait_pattern_passes_the_capture_rule():
+    """The N > 1 step adds producer -> comm-stream and comm-stream -> origin waits (dp.GradReducer._launch / finish);
+    they go through streams.py, so the capture rule (no mutual waits between forked streams) polices them.  World size 1
+    through the real reducer path (what bench.py --force-reducer runs): the capture must succeed and replay."""
+    import torch_detection_amd as T
+    from torch_detection_amd import dp
+    from torch_detection_amd.graph import GraphedStep
+    dev = torch.device("cuda", 0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        rb, rf = T.ResNet(50), T.FPN([256, 512, 1024, 2048], 256, 5)
+        rb.load_state_dict(fill_state_dict(rb.state_dict(), 60))
+        rf.load_state_dict(fill_state_dict(rf.state_dict(), 61))
+        rb.to(dev).train()
+        rf.to(dev)
+        x = det_tensor((2, 3, 128, 160), 720, -2, 2).to(dev)
+        red = dp.attach_reducer([rf, rb], bucket_bytes=8 << 20)
+        assert red.enabled and red.use_streams and len(red.buckets) >= 3
+        params = [p for p in list(rb.parameters()) + list(rf.parameters()) if p.requires_grad]
+
+        def step():
+            outs = rf(rb(x))
+            torch.autograd.backward([o.float().sum() for o in outs])
+            red.finish()
+
+        gs = GraphedStep(step, warmup=2, verbose=True)
+        assert gs.captured, "capture with the reducer fell back to eager: %r" % (gs.error,)
+        gs()
+        torch.cuda.synchronize()
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)
+    finally:
+        dist.destroy_process_group()

@@ -106,18 +106,19 @@ def test_full_size_schedules_agree(T, depth, batch, dtype, monkeypatch):
     assert all(torch.equal(p.grad, g) for p, g in zip(params, g_def))
 
 
-@pytest.mark.parametrize("depth,batch,dtype", [(50, 2, torch.bfloat16), (101, 1, torch.float16)],
-                         ids=["r50_bf16_b2", "r101_f16_b1"])
+@pytest.mark.parametrize("depth,batch,dtype", [(50, 2, torch.bfloat16), (50, 1, torch.bfloat16), (101, 1, torch.float16)],
+                         ids=["r50_bf16_b2", "r50_bf16_b1", "r101_f16_b1"])
 def test_full_size_in_situ(T, depth, batch, dtype):
     """Every launch of the 800x1344 forward and backward against the CPU schedule oracle on the GPU's own operands
-    (R101 / float16: one image — the CPU side recomputes ~1.4 TFLOP per image)."""
+    (R101 / float16: one image — the CPU side recomputes ~1.4 TFLOP per image).  r50_bf16_b1 is BASELINE config C2 at
+    its own batch (one image: the stem and FPN launches get the tile plans of M = 67,200 instead of 134,400)."""
     import json
     import parity_util
     deep = dtype == torch.float16
     res = parity_util.run_teacher_forced(T, depth, (batch, 3, H, W), dtype=dtype, end_to_end=False,
                                          cot_scale=2.0 ** -6 if deep else 1.0, res_gain=0.25 if deep else 1.0)
     if os.path.isdir("gpurun_out"):
-        with open("gpurun_out/parity_fullsize_r%d.json" % depth, "w") as f:
+        with open("gpurun_out/parity_fullsize_r%d_b%d.json" % (depth, batch), "w") as f:
             json.dump(res, f, indent=1, default=float)
     f, b = res["forward_in_situ"], res["backward_in_situ"]
     assert max(f.values()) <= parity_util.FWD_IN_SITU_TOL, f

@@ -478,12 +478,12 @@ extern "C" int tdn_nms(const float* boxes, const float* scores, int N, float iou
   const bool one_wave = getenv("TDN_NMS_ONEWAVE") && getenv("TDN_NMS_ONEWAVE")[0] == '1';   // A/B runs
   if (nblk <= NMS_BLOCK_MAX_NBLK && !one_wave) {
     const size_t lds = (size_t)(((nblk + 1) & ~1) + NMS_SC * NMS_DPITCH + NMS_SC) * 8 + NMS_SCROWS * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static tdn_attr_once attr_once;
+    if (attr_once.need()) {
       hipError_t e = hipFuncSetAttribute((const void*)nms_scan_block_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(nms scan LDS) failed: %s", hipGetErrorString(e));
-      attr_set = true;
+      attr_once.mark();
     }
     TDN_LAUNCH(nms_scan_block_kernel, dim3(1), dim3(1024), lds, st, mask, order, N, nblk, keep, kept_idx,
                        num_kept);

@@ -163,6 +163,19 @@ static __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
 __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute (dynamic LDS beyond 64 KB) applies to ONE device: remembered per kernel instantiation AND device
+// (`static tdn_attr_once once; if (once.need()) { ...set...; once.mark(); }`), so that a second GPU used from the same
+// process does not launch without it.
+struct tdn_attr_once {
+  bool done[64] = {};
+  int dev = 0;
+  bool need() {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { dev = -1; return true; }
+    return !done[dev];
+  }
+  void mark() { if (dev >= 0) done[dev] = true; }
+};
+
 // XCD-aware bijective remap: blocks b, b+8, b+16.. share an XCD (observed round-robin placement,
 // speed only) -> give each XCD a contiguous chunk of tile ids so neighbours share L2 lines.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

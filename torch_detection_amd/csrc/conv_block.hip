@@ -931,14 +931,12 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
 template <bool BWD, bool F16>
 static int launch_block64(BlockParams& p, hipStream_t stream) {
   constexpr int lds = 81920;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+  static tdn_attr_once attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)bottleneck64_kernel<BWD, F16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
-    attr_set[dev] = true;
+    attr_once.mark();
     if (getenv("TDN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bottleneck64_kernel<BWD, F16>, 256, lds);
@@ -958,14 +956,12 @@ extern "C" int tdn_debug_block_trace(void* buf) { g_blk_trace = (unsigned long l
 template <bool BWD, bool F16>
 static int launch_block128(BlockParams& p, hipStream_t stream) {
   constexpr int lds = 163840;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+  static tdn_attr_once attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)bottleneck128_kernel<BWD, F16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
-    attr_set[dev] = true;
+    attr_once.mark();
   }
   TDN_LAUNCH((bottleneck128_kernel<BWD, F16>), dim3(p.nwg_pad), dim3(512), lds, stream, p);
   TDN_LAUNCH_CHECK();

@@ -712,12 +712,12 @@ static bool halo_make_plan(const HaloShape& s, HaloPlan* pl) {
 
 template <int FM, int FN, int WM, int WN, int NST, int NTAPS, int XI9, bool F16, int ABL = 0, int NWL = 0>
 static int halo_launch(const HaloParams& p, size_t lds, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tdn_attr_once attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<FM, FN, WM, WN, NST, NTAPS, XI9, F16, ABL, NWL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(halo kernel LDS) failed: %s", hipGetErrorString(e));
-    attr_set = true;
+    attr_once.mark();
   }
   dim3 grid(p.nwg_pad, 1, 1), block((WM * WN + NWL) * 64, 1, 1);
   TDN_LAUNCH((conv_halo_kernel<FM, FN, WM, WN, NST, NTAPS, XI9, F16, ABL, NWL>), grid, block, lds, stream, p);

@@ -1076,12 +1076,12 @@ static int launch_gemm(GemmParams& p, int maxM, hipStream_t stream) {
   const int ntiles = ceil_div(maxM, BM) * p.tiles_n;
   p.nwg_pad = (ntiles + 7) & ~7;
   constexpr size_t lds = (size_t)KG * NSTAGE * (BM + BN) * BK * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tdn_attr_once attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, BK, WM, WN, NSTAGE, MODE, TAG, KG, F16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
-    attr_set = true;
+    attr_once.mark();
     if (getenv("TDN_DEBUG_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(

@@ -1077,12 +1077,12 @@ static int plan_group(const tdn_wgrad_item* items, int n, std::vector<ItemPlan>&
 template <int BMW, int BNW, int WM, int WN, int NST, bool F16>
 static int launch_tap_t(const WgGroup& grp, int nblocks, hipStream_t stream) {
   constexpr size_t lds = (size_t)NST * 64 * (BMW + BNW) * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tdn_attr_once attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_group_kernel<BMW, BNW, WM, WN, NST, F16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
-    attr_set = true;
+    attr_once.mark();
   }
   TDN_LAUNCH((conv_wgrad_group_kernel<BMW, BNW, WM, WN, NST, F16>), dim3(nblocks), dim3(WM * WN * 64), lds,
                      stream, grp);
@@ -1109,12 +1109,12 @@ static int launch_tap(int shape, const WgGroup& grp, int nblocks, hipStream_t st
 template <bool F16, int WMR>
 static int launch_t9(const WgGroup& grp, int nblocks, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)(64 * (64 * WMR) + 3 * 72 * 128);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tdn_attr_once attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_group_kernel<F16, WMR>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", (int)lds, hipGetErrorString(e));
-    attr_set = true;
+    attr_once.mark();
   }
   TDN_LAUNCH((conv_wgrad9_group_kernel<F16, WMR>), dim3(nblocks), dim3(WMR * 128), lds, stream, grp);
   TDN_LAUNCH_CHECK();

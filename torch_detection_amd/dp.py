@@ -29,6 +29,8 @@ supported in this mode (use the plain autograd path, which accumulates as usual)
 import torch
 import torch.distributed as dist
 
+from . import streams
+
 
 class GradReducer(object):
     """Flat-buffer bucketed all-reduce.  ``numels``: gradient sizes in the order they become ready."""
@@ -119,10 +121,10 @@ class GradReducer(object):
             # the bucket's gradients were produced on several streams (the weight-gradient kernels rotate over a
             # pool of side streams): the comm stream waits for every one of them — and for the current stream, which
             # covers buckets flushed from finish() and gradients written by the main stream
+            # (through streams.py: the capture rule — no mutual waits between forked streams — is asserted there, and a
+            # launch plan being recorded learns of the dependency)
             for st in list(self._producers[b].values()) + [torch.cuda.current_stream(self.device)]:
-                ev = torch.cuda.Event()
-                ev.record(st)
-                self.comm_stream.wait_event(ev)
+                streams.wait_stream(self.comm_stream, st)
             with torch.cuda.stream(self.comm_stream):
                 if wire is not buf:
                     wire.copy_(buf)            # fp32 -> 16-bit, round to nearest even, on the comm stream
@@ -153,7 +155,7 @@ class GradReducer(object):
         for w in self._works:
             w.wait()
         if self.use_streams and self.enabled:
-            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            streams.wait_stream(torch.cuda.current_stream(self.device), self.comm_stream)
         scale = 1.0 / self.world if (self.average and self.world > 1 and not self._avg_in_collective) else None
         if self.comm_buf is not None and self.enabled:
             # 16-bit sums back into the fp32 gradient views, the 1/world average folded into the same pass
@@ -162,7 +164,9 @@ class GradReducer(object):
                 if scale is None:
                     self.flat[start:end].copy_(self.comm_buf[start:end])
                 else:
-                    torch.mul(self.comm_buf[start:end], scale, out=self.flat[start:end])
+                    # widen first, scale in fp32: torch.mul(16-bit, scalar, out=fp32) computes in the 16-bit type and
+                    # rounds the product once more (bf16 1.0 / 3 -> 0.33398) for world sizes that are not powers of two
+                    self.flat[start:end].copy_(self.comm_buf[start:end]).mul_(scale)
         elif scale is not None:
             # only the reduced buckets carry a sum; one pass over them (no pass at all when the collective averaged)
             for b in (self._launched if self.enabled else range(len(self.buckets))):

@@ -926,8 +926,10 @@ def _blocks_fwd_split(blocks, cur):
     # nodes — a few hundred microseconds unprofiled, ~0.7 ms under rocprofv3, which is what its timelines show.)
     xs = [cur[cuts[i]:cuts[i + 1]] for i in range(ways)]
     # TDN_CHAIN_SYNC=n (diagnostic, default off): every n blocks each chain waits for the other chains' progress up to
-    # that block (a per-block cross-join, meant to make a replayed graph interleave the chains).  See DESIGN.md §6:
-    # hipGraphInstantiate of a capture with such joins died in round 2; kept as a knob to reproduce it with stderr.
+    # that block (a per-block cross-join, meant to make a replayed graph interleave the chains).  Mode 'cross' (mutual
+    # waits between the two forked streams) is the pattern that crashed hipStreamEndCapture in round 2; inside a
+    # GraphedStep capture streams.wait now refuses it with a RuntimeError (the step then runs eager) — to reproduce the
+    # crash itself, capture with a plain torch.cuda.graph (not policed).
     chain_sync = int(os.environ.get('TDN_CHAIN_SYNC', '0'))
     for bi_, (b, (h1, h2, out, res)) in enumerate(zip(blocks, bufs)):
         if chain_sync > 0 and bi_ > 0 and bi_ % chain_sync == 0:

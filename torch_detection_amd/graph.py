@@ -108,10 +108,16 @@ class GraphedStep(object):
             # thread_local: other threads (the process group's watchdog, the allocator's helpers) are not policed
             # during the capture; the launches autograd's device thread makes into the capturing streams are captured
             # either way
+            # capture on the stream the warm-up ran on: per-(device, stream) state created during warm-up — the
+            # split-K scratch of ops.splitk_workspace, the side / chain stream pools of functional.py — is keyed by the
+            # raw stream and must be found again inside the capture (nothing may be allocated there)
             from . import streams
-            streams.capture_started()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                fn()
+            streams.capture_started(side.cuda_stream)
+            try:
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    fn()
+            finally:
+                streams.capture_finished()
             self.graph = g
         except Exception as e:  # noqa: BLE001 - fall back loudly, never silently
             self.error = e
@@ -160,6 +166,7 @@ class PreparedStep(object):
         from . import _lib, functional as HF
         self.fn = fn
         self.plan = None
+        self.foreign = 0
         self.error = None
         self.pool = None
         self._lib = _lib.load()
@@ -185,6 +192,12 @@ class PreparedStep(object):
             if not self.plan:
                 _lib.check(-1, "tdn_plan_end")
             torch.cuda.synchronize()
+            self.stats()
+            if self.foreign > 0:
+                # launches another thread made while the plan was recorded are counted, not kept: a replay of this plan
+                # would silently skip them
+                raise RuntimeError("%d launch(es) of the recorded step came from another thread and are not in the "
+                                   "plan (recording binds to the recording thread)" % self.foreign)
             if params is not None:
                 ref = [p.grad.clone() if p.grad is not None else None for p in params]
                 for p in params:
@@ -216,7 +229,7 @@ class PreparedStep(object):
         """(launches, event records, stream waits) of the plan."""
         import ctypes
         out = (ctypes.c_int32 * 3)()
-        self._lib.tdn_plan_stats(self.plan, out)
+        self.foreign = int(self._lib.tdn_plan_stats(self.plan, out))
         return tuple(out)
 
     def __call__(self):
