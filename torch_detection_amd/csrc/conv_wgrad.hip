@@ -528,13 +528,20 @@ __global__ __launch_bounds__(WMR * 128) void conv_wgrad9_group_kernel(const WgGr
     stage_load(m_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // The two waves of a SIMD (w and w + NWV / 2) run the same program between the same barriers: left alone they
+    // issue their LDS-DMA pieces (each holds the wave's issue slot for ~100-250 cycles) at the same time and their
+    // MFMAs at the same time.  The second half of the waves issues the next K-step's pieces between the two 32-pixel
+    // sub-steps instead, so that on every SIMD one wave's DMA issue runs beside the other's MFMAs (TDN_WGRAD9_STAGGER=0:
+    // all waves at the top).
+    const bool late_issue = grp.reserved != 0 && wave >= NWV / 2;
     for (int t = 0; t < T; ++t) {
-      if (t + 1 < T) stage_load(m_begin + (t + 1) * BKW, (t + 1) & 1);
+      if (!late_issue && t + 1 < T) stage_load(m_begin + (t + 1) * BKW, (t + 1) & 1);
       const char* sG = smem + (t & 1) * STAGE;
       const char* sX = sG + G_TILE;
       const bool line_end = (mw == 0) || (mw + BKW >= W);     // some pixel of this K-step sits in column 0 or W-1
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
+        if (kk == 1 && late_issue && t + 1 < T) stage_load(m_begin + (t + 1) * BKW, (t + 1) & 1);
         bf16x8_t gf[3][FM];                                   // [dw + 1]
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -1188,6 +1195,7 @@ extern "C" int tdn_wgrad_group(const tdn_wgrad_item* items, int n, void* workspa
     WgGroup grp;
     memset(&grp, 0, sizeof(grp));
     grp.nitems = (int)L.size();
+    grp.reserved = env_int("TDN_WGRAD9_STAGGER", 1);   // nine-tap kernel: staggered LDS-DMA issue (see the kernel)
     int blk = 0;
     for (int j = 0; j < WG_MAXI + 2; ++j) grp.blk_start[j] = INT_MAX;
     for (int j = 0; j < (int)L.size(); ++j) {
