@@ -55,10 +55,17 @@ torch.cuda.synchronize()
 lib.tdn_debug_block_trace(ctypes.c_void_p(0))
 t = buf.cpu().numpy().reshape(nwg, 16).astype(np.int64)
 t = t[t[:, 0] != 0]
-names = ["entry->first K-step landed", "K-steps 0-3", "K-steps 4-7 (b0)", "epilogue 1 + b1 (taps 2-6 landed)", "taps 0,1 + b2",
-         "taps 2-6 + b3", "taps 7,8 + b4", "epilogue 2 + b5 (W3 landed)", "pass 0 MFMA + epilogue math", "pass 1 MFMA + epilogue math",
-         "last stores issued", "stores drained"]
-d = np.diff(t[:, :13], axis=1)
+if C == 64:
+    names = ["entry->first K-step landed", "K-steps 0-3", "K-steps 4-7 (b0)", "epilogue 1 + b1 (taps 2-6 landed)", "taps 0,1 + b2",
+             "taps 2-6 + b3", "taps 7,8 + b4", "epilogue 2 + b5 (W3 landed)", "pass 0 MFMA + epilogue math", "pass 1 MFMA + epilogue math",
+             "last stores issued", "stores drained"]
+    cols = list(range(13))
+else:
+    names = ["entry->first K-step landed", "K-steps 0-7", "K-steps 8-15 (b0)", "epilogue 1, stores, unit 0 wait", "units 0-8",
+             "units 9-17 + b4", "addend loads, epilogue 2, b5", "pass 0 MFMA + b6 + epilogue math", "stores, b7, pass 1 + epilogue math",
+             "last stores issued", "stores drained"]
+    cols = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12]
+d = np.diff(t[:, cols], axis=1)
 tot = t[:, 12] - t[:, 0]
 print("%d workgroups; cycles per segment: median / p10 / p90; share of the median lifetime %d cycles" % (t.shape[0], np.median(tot)))
 for i, nm in enumerate(names):

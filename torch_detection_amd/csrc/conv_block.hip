@@ -743,13 +743,33 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
     o3p[j] = ok ? p.o3 + pix * C4 + chw : (bf16_t*)g_blk_sink;
     o2p[j] = ok ? p.o2 + pix * C + cb8 : (bf16_t*)g_blk_sink;
   }
+  // Phase 3's per-pixel operands (addend, ReLU-mask source).  Loads return in issue order, so a load issued behind a
+  // batch of LDS-DMA units is not back before those have landed: the first pass's operands are requested in the middle
+  // of phase 2 (8 or 16 unconditional loads, accounted for in the counted waits of the six iterations in which they
+  // are younger than the awaited unit), the second pass's addend right behind phase 2.
+  bf16x8_t ad0[4][2], ad1[4][2], mk3[4][2];
+  constexpr int NADD = BWD ? 16 : 8;
+  auto load_mask3 = [&](int nc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) mk3[j][h] = *(const bf16x8_t*)(mkp[j] + nc * 256 + h * 8);
+  };
 #pragma unroll
   for (int u = 0; u < 18; ++u) {
     // unit u landed for every wave; the slot of unit u - 1 is free.  In flight behind it: units u + 1 .. u + 5
     // (u = 0: .. u + 6), two LDS-DMA instructions each
     if (u == 0) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // + H1 complete
+    else if (u >= 10 && u <= 15) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(10 + NADD) : "memory");
     else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (u >= 1) load_unit(u + 6);
+    if (u == 9) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) ad0[j][h] = *(const bf16x8_t*)(adp[j] + h * 8);
+      if constexpr (BWD) load_mask3(0);
+    }
     if (u == 0) BLK_STAMP(4);
     if (u == 9) BLK_STAMP(5);
     const int h = u / 9, t = u - h * 9;
@@ -774,18 +794,16 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
   }
   lds_barrier();   // b4: H1 is dead; the slot of unit 17 is free
   BLK_STAMP(6);
-  // first pass's addend / mask / affine: in front of unit 24, so that b5's counted wait covers them
-  bf16x8_t ad[4][2], mk3[4][2];
-  auto load_addend = [&](int nc) {
+  // second pass's addend (forward; the backward pass, which also carries mask operands, has no registers to spare and
+  // requests it with the second mask after the first pass), first pass's affine: in front of unit 24, so that b5's
+  // counted wait covers them
+  auto load_ad1 = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        ad[j][h] = *(const bf16x8_t*)(adp[j] + nc * 256 + h * 8);
-        if constexpr (BWD) mk3[j][h] = *(const bf16x8_t*)(mkp[j] + nc * 256 + h * 8);
-      }
+      for (int h = 0; h < 2; ++h) ad1[j][h] = *(const bf16x8_t*)(adp[j] + 256 + h * 8);
   };
-  load_addend(0);
+  if constexpr (!BWD) load_ad1();
   f32x4_t sc3v[4], sh3v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, chw + 4 * i, sc3v[i], sh3v[i]);
@@ -874,8 +892,8 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[2 * h][e] += elem_to_f32<F16>(ad[j][h][e]);
-          v[2 * h + 1][e] += elem_to_f32<F16>(ad[j][h][4 + e]);
+          v[2 * h][e] += elem_to_f32<F16>((nc == 0 ? ad0 : ad1)[j][h][e]);
+          v[2 * h + 1][e] += elem_to_f32<F16>((nc == 0 ? ad0 : ad1)[j][h][4 + e]);
         }
       if constexpr (BWD) {
         const bool has_m3 = p.m3 != nullptr;
@@ -903,7 +921,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
     BLK_STAMP(9 + nc);
     __builtin_amdgcn_sched_barrier(0);
     if (nc == 0) {
-      load_addend(1);
+      if constexpr (BWD) { load_ad1(); load_mask3(1); }
 #pragma unroll
       for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, 256 + chw + 4 * i, sc3v[i], sh3v[i]);
 #pragma unroll
@@ -913,9 +931,9 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int h = 0; h < 2; ++h) *(bf16x8_t*)(o3p[j] + nc * 256 + h * 8) = ov[j][h];
-    // b7: units 22..25 landed.  Behind unit 25 this wave has issued 8 addend loads (+ 8 mask loads, or up to 8 affine
-    // loads), 4 + 8 stores — all unconditional (sink / zero-page redirect): at least 20 younger operations
-    if (nc == 0) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // b7: units 22..25 landed.  Behind unit 25 this wave has issued 8 + 8 addend and mask loads (backward) or up to 8
+    // affine loads (forward: none if there is no BN), then 4 + 8 stores — all unconditional (sink / zero-page redirect)
+    if (nc == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(BWD ? 28 : 12) : "memory");
   }
 #ifdef TDN_TRACE_BUILD
   BLK_STAMP(11);
