@@ -292,6 +292,41 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     }
   }
 
+  // Phase 3's per-pixel operands are requested HERE, a whole phase ahead: loads return in issue order, so behind a
+  // batch of LDS-DMA they would not be back before it has landed, and their first use sits behind b3 / b5, where the
+  // queue is drained anyway.  Forward: both passes' addends; backward (which also carries mask operands): the first
+  // pass's addend and mask, the second pass's after the first pass.
+  const int chw = wn * 64 + fq * 16;       // + nc * 128: this lane's 16 consecutive output channels
+  // Loads and stores of output pixels outside the image (ragged tiles) are redirected to the zero page / a sink line
+  // instead of being branched around: see g_blk_sink.
+  const bf16_t* adp[4];
+  const bf16_t* mkp[4];
+  bf16_t* o3p[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int y = y0 + wm * 4 + j, x = x0 + fr;
+    const bool ok = (y < H) && (x < W);
+    const int64_t off = (img_pix0 + (int64_t)y * W + x) * C4 + chw;
+    adp[j] = ok ? p.a + off : (const bf16_t*)g_blk_zero;
+    mkp[j] = (ok && p.m3) ? p.m3 + off : (const bf16_t*)g_blk_zero;
+    o3p[j] = ok ? p.o3 + off : (bf16_t*)g_blk_sink;
+  }
+  bf16x8_t ad0[4][2], ad1[4][2], mk3[4][2];
+  auto load_ad = [&](int nc, bf16x8_t (&dst)[4][2]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) dst[j][h] = *(const bf16x8_t*)(adp[j] + nc * 128 + h * 8);
+  };
+  auto load_mask3 = [&](int nc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) mk3[j][h] = *(const bf16x8_t*)(mkp[j] + nc * 128 + h * 8);
+  };
+  load_ad(0, ad0);
+  if constexpr (BWD) load_mask3(0); else load_ad(1, ad1);
+
   // ================= phase 2: H2[8x16][C] =================
   f32x4_t acc2[2][4];
 #pragma unroll
@@ -335,33 +370,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     const int n = g8 * 8 + lrow8;
     glds16_async((const char*)p.w3 + (int64_t)n * C * 2 + ((lchunk8 ^ swz_w16(n)) * 16), smem + W3_OFF + g8 * 8 * ROWB);
   }
-  // addend (and mask) of the first 128 output channels: requested now, consumed after phase 3's first pass
-  const int chw = wn * 64 + fq * 16;       // + nc * 128: this lane's 16 consecutive output channels
-  // Loads and stores of output pixels outside the image (ragged tiles) are redirected to the zero page / a sink line
-  // instead of being branched around: see g_blk_sink.
-  const bf16_t* adp[4];
-  const bf16_t* mkp[4];
-  bf16_t* o3p[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int y = y0 + wm * 4 + j, x = x0 + fr;
-    const bool ok = (y < H) && (x < W);
-    const int64_t off = (img_pix0 + (int64_t)y * W + x) * C4 + chw;
-    adp[j] = ok ? p.a + off : (const bf16_t*)g_blk_zero;
-    mkp[j] = (ok && p.m3) ? p.m3 + off : (const bf16_t*)g_blk_zero;
-    o3p[j] = ok ? p.o3 + off : (bf16_t*)g_blk_sink;
-  }
-  bf16x8_t ad[4][2], mk3[4][2];
-  auto load_addend = [&](int nc) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        ad[j][h] = *(const bf16x8_t*)(adp[j] + nc * 128 + h * 8);
-        if constexpr (BWD) mk3[j][h] = *(const bf16x8_t*)(mkp[j] + nc * 128 + h * 8);
-      }
-  };
-  load_addend(0);
   f32x4_t sc2v[2], sh2v[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) load_affine(p.sc2, p.sh2, cb8 + 4 * i, sc2v[i], sh2v[i]);
@@ -442,8 +450,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[2 * h][e] += elem_to_f32<F16>(ad[j][h][e]);
-            v[2 * h + 1][e] += elem_to_f32<F16>(ad[j][h][4 + e]);
+            v[2 * h][e] += elem_to_f32<F16>((nc == 0 ? ad0 : ad1)[j][h][e]);
+            v[2 * h + 1][e] += elem_to_f32<F16>((nc == 0 ? ad0 : ad1)[j][h][4 + e]);
           }
         if constexpr (BWD) {
           const bool has_m3 = p.m3 != nullptr;   // no mask: the select below keeps every value
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       BLK_STAMP(9 + nc);
       __builtin_amdgcn_sched_barrier(0);
       if (nc == 0) {   // the second pass's operands travel while the first pass's results are stored
-        load_addend(1);
+        if constexpr (BWD) { load_ad(1, ad1); load_mask3(1); }
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, 128 + chw + 4 * i, sc3v[i], sh3v[i]);
 #pragma unroll
