@@ -220,6 +220,13 @@ typedef struct tdn_bottleneck_args {
   void* out2;           /* [N][H][W][C] */
   void* out3;           /* [N][H][W][4C] */
   int32_t N, H, W, C;
+  /* ReLU bit planes, optional (all NULL = off): 1 bit per element, bit c % 32 of the 32-bit word c / 32 of the pixel.
+   *   forward: written —  bits1 = out1 > 0, bits2 = out2 > 0, bits3 = in > 0 (any subset)
+   *   dgrad:   read INSTEAD of mask1 / mask2 / mask3 (all three or none): bits2 masks out1, bits1 masks out2, bits3
+   *            masks out3 — i.e. the three planes the forward call of the same block wrote.  1/16 of the mask bytes. */
+  void* bits1;          /* [N][H][W][C / 32]  uint32 */
+  void* bits2;          /* [N][H][W][C / 32]  uint32 */
+  void* bits3;          /* [N][H][W][4C / 32] uint32 */
 } tdn_bottleneck_args;
 int tdn_bottleneck_supported(int H, int W, int C, int stride, int dilation);
 int tdn_bottleneck_fwd(const tdn_bottleneck_args* a, int dtype, void* stream);

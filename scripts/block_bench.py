@@ -70,8 +70,17 @@ def main():
         r2 = ops.conv2d_fwd(r1, w2, 3, 1, 1, aff[2], aff[3], relu=True, out=o2)
         ops.conv2d_fwd(r2, w3, 1, 1, 0, aff[4], aff[5], x, ops.ADD_SAME, True, out=o3)
 
+    bits = ops.bottleneck_bit_planes(N, H, W, C, dev)
+    ops.bottleneck_fwd(x, w1, w2, w3, aff, bits=bits)
+
+    def fused_fb():
+        ops.bottleneck_fwd(x, w1, w2, w3, aff, outs=(o1, o2, o3), bits=bits)
+
     def fused_b():
         ops.bottleneck_dgrad(g, w3d, w2d, w1d, (h2, h1, x), outs=(o1, o2, o3))
+
+    def fused_bb():
+        ops.bottleneck_dgrad(g, w3d, w2d, w1d, None, outs=(o1, o2, o3), bits=bits)
 
     def sep_b():
         r2 = ops.conv2d_dgrad(g, w3d, (H, W), 1, 1, 0, mask_src=h2, out=o1)
@@ -81,10 +90,11 @@ def main():
     gflop = 2.0 * N * H * W * (C4 * C + 9 * C * C + C * C4) / 1e9
     mb_fused = N * H * W * (C4 + C + C + C4) * 2 / 1e6
     print("bottleneck C=%d, %d x %dx%d: %.2f GFLOP, %.0f MB (x once, h1 / h2 written, out written)" % (C, N, H, W, gflop, mb_fused))
-    for name, f, s in (("forward", fused_f, sep_f), ("dgrad", fused_b, sep_b)):
+    for name, f, s in (("forward", fused_f, sep_f), ("fwd+bits", fused_fb, sep_f), ("dgrad", fused_b, sep_b),
+                       ("dgrad/bits", fused_bb, sep_b)):
         tf = timeit(f, a.iters)
         ts = timeit(s, a.iters)
-        print("%-8s one launch %7.1f us (%5.0f TF/s, %4.2f TB/s)   three launches %7.1f us   x%.2f" %
+        print("%-10s one launch %7.1f us (%5.0f TF/s, %4.2f TB/s)   three launches %7.1f us   x%.2f" %
               (name, tf, gflop / tf * 1e3, mb_fused / tf, ts, ts / tf))
 
 

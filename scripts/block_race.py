@@ -31,7 +31,8 @@ r3 = ops.conv2d_fwd(r2, w3g, 1, 1, 0, affg[4], affg[5], xg, ops.ADD_SAME, True)
 torch.cuda.synchronize()
 bad_runs = 0
 for rep in range(int(os.environ.get("REPS", 30))):
-    h1, h2, out = ops.bottleneck_fwd(xg, w1g, w2g, w3g, affg)
+    bits = ops.bottleneck_bit_planes(N, H, W, C, dev)
+    h1, h2, out = ops.bottleneck_fwd(xg, w1g, w2g, w3g, affg, bits=bits)
     torch.cuda.synchronize()
     msg = []
     for name, a, b in (("h1", h1, r1), ("h2", h2, r2), ("out", out, r3)):

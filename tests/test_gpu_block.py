@@ -173,7 +173,9 @@ def test_block_baseline_geometry(ops, generic_tiles, rep, H, W, C):
     w1d, w2d, w3d = (w.permute(3, 1, 2, 0).contiguous() for w in (w1g, w2g, w3g))
     g = torch.where(out > 0, (det_tensor((N, H, W, 4 * C), 777) * 0.1).to(dtype).to(dev), torch.zeros((), device=dev, dtype=dtype))
     g = g.contiguous()
-    g2, g1, dx = ops.bottleneck_dgrad(g, w3d, w2d, w1d, (h2, h1, xg))
+    bits = ops.bottleneck_bit_planes(N, H, W, C, dev)
+    ops.bottleneck_fwd(xg, w1g, w2g, w3g, affg, bits=bits)
+    g2, g1, dx = ops.bottleneck_dgrad(g, w3d, w2d, w1d, None, bits=bits)        # the production form: bit planes
     q2 = ops.conv2d_dgrad(g, w3d, (H, W), 1, 1, 0, mask_src=h2)
     q1 = ops.conv2d_dgrad(q2, w2d, (H, W), 3, 1, 1, mask_src=h1)
     qx = ops.conv2d_dgrad(q1, w1d, (H, W), 1, 1, 0, g, ops.ADD_SAME, xg)
@@ -183,3 +185,41 @@ def test_block_baseline_geometry(ops, generic_tiles, rep, H, W, C):
         if bool(ne.any()):
             idx = ne.nonzero()[:8].tolist()
             raise AssertionError("%s: %d of %d elements differ, first at (n, y, x, c) %s" % (name, int(ne.sum()), a.numel(), idx))
+
+
+def _unpack_bits(b, ch):
+    """[N][H][W][ch / 32] int32 words -> bool [N][H][W][ch] (bit c % 32 of word c / 32)."""
+    w = b.cpu().to(torch.int64) & 0xFFFFFFFF
+    sh = torch.arange(32, dtype=torch.int64)
+    bits = ((w.unsqueeze(-1) >> sh) & 1).bool()
+    return bits.reshape(*b.shape[:3], ch)
+
+
+@pytest.mark.parametrize("C", [64, 128])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W", [(1, 16, 32), (2, 13, 21), (1, 17, 40)])
+def test_block_relu_bit_planes(ops, generic_tiles, N, H, W, dtype, C):
+    """The forward kernel's ReLU bit planes are exactly (h1 > 0), (h2 > 0), (x > 0) of the stored 16-bit tensors, and
+    the backward kernel driven by them is bit-identical to the one driven by the 16-bit mask sources."""
+    x, w1, w2, w3, aff = _case(N, H, W, C, dtype, 300 * H + W + C)
+    dev = torch.device("cuda")
+    xg, w1g, w2g, w3g = (t.contiguous().to(dev) for t in (x, w1, w2, w3))
+    affg = [a.to(dev) for a in aff]
+    bits = ops.bottleneck_bit_planes(N, H, W, C, dev)
+    for b in bits:
+        b.fill_(0x5A5A5A5A)            # poison: every word must be written
+    h1, h2, out = ops.bottleneck_fwd(xg, w1g, w2g, w3g, affg, bits=bits)
+    r1, r2, r3 = ops.bottleneck_fwd(xg, w1g, w2g, w3g, affg)
+    torch.cuda.synchronize()
+    for a, b in ((h1, r1), (h2, r2), (out, r3)):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))       # the planes do not perturb the outputs
+    for name, b, ref, ch in (("h1", bits[0], h1, C), ("h2", bits[1], h2, C), ("x", bits[2], xg, 4 * C)):
+        assert torch.equal(_unpack_bits(b, ch), (ref.float().cpu() > 0)), name
+    w1d, w2d, w3d = (w.permute(3, 1, 2, 0).contiguous() for w in (w1g, w2g, w3g))
+    g = torch.where(out > 0, (det_tensor((N, H, W, 4 * C), 991) * 0.1).to(dtype).to(dev), torch.zeros((), device=dev, dtype=dtype))
+    g = g.contiguous()
+    a2, a1, ax = ops.bottleneck_dgrad(g, w3d, w2d, w1d, (h2, h1, xg))
+    b2, b1, bx = ops.bottleneck_dgrad(g, w3d, w2d, w1d, None, bits=bits)
+    torch.cuda.synchronize()
+    for name, a, b in (("g2", a2, b2), ("g1", a1, b1), ("dx", ax, bx)):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), name

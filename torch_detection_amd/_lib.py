@@ -94,7 +94,8 @@ class BottleneckArgs(ctypes.Structure):
                 ("scale3", c_void_p), ("shift3", c_void_p),
                 ("mask1", c_void_p), ("mask2", c_void_p), ("mask3", c_void_p),
                 ("out1", c_void_p), ("out2", c_void_p), ("out3", c_void_p),
-                ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32)]
+                ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("bits1", c_void_p), ("bits2", c_void_p), ("bits3", c_void_p)]
 
 
 _BA = ctypes.POINTER(BottleneckArgs)

@@ -50,6 +50,11 @@ struct BlockParams {
   bf16_t* o1;          // [N][H][W][C]    h1 / g2
   bf16_t* o2;          // [N][H][W][C]    h2 / g1
   bf16_t* o3;          // [N][H][W][4C]   out / dx
+  // ReLU bit planes (1 bit per element, bit c % 32 of word c / 32 of the pixel's run of words): written by the forward
+  // pass when given, read by the backward pass INSTEAD of the 16-bit mask sources m1 / m2 / m3
+  unsigned* b1;        // [N][H][W][C / 32]    h1 > 0   (backward: mask of its phase 2 output)
+  unsigned* b2;        // [N][H][W][C / 32]    h2 > 0   (backward: mask of its phase 1 output, read on the halo too)
+  unsigned* b3;        // [N][H][W][4C / 32]   x > 0    (backward: mask of its phase 3 output)
   int N, H, W;
   int tiles_x, tiles_y, ntiles, nwg_pad;
   unsigned long long* trace;   // libtdn_trace.so only: 16 x 8-byte stamps per workgroup (scripts/block_trace.py)
@@ -75,13 +80,30 @@ struct BlockParams {
 static __device__ __attribute__((aligned(256))) unsigned char g_blk_sink[512];
 static __device__ __attribute__((aligned(256))) unsigned char g_blk_zero[512];   // load source of such pixels (a lane reads up to 288 B behind its base)
 
+// bit e of the result: element e of v is > 0 (what the ReLU masks of the backward pass test)
+template <bool F16>
+__device__ __forceinline__ unsigned pos_bits8(bf16x8_t v) {
+  unsigned m = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m |= (elem_to_f32<F16>(v[e]) > 0.f) ? (1u << e) : 0u;
+  return m;
+}
+// the four lanes fr, fr + 16, fr + 32, fr + 48 (fq = 0..3) each hold one byte of a pixel's 32-channel word: every lane
+// gets the whole word
+__device__ __forceinline__ unsigned gather_word4(unsigned byte, int fq) {
+  unsigned w = byte << (8 * fq);
+  w |= __shfl_xor(w, 16);
+  w |= __shfl_xor(w, 32);
+  return w;
+}
+
 // Workgroup barrier that is also a compiler barrier for memory operations and retires this wave's LDS reads first.
 // The raw __builtin_amdgcn_s_barrier() orders nothing for the compiler: a ds_write into a region other waves were
 // still reading before the barrier (H1 over ring slots 2 / 3, H2 over H1) may be hoisted above it — seen as a
 // timing-dependent mismatch at 525 co-resident workgroups, never at small grids.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool BWD, bool F16>
+template <bool BWD, bool F16, bool MB = false>
 __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int C = 64, C4 = 256, TH = 8, TW = 16, HWD = TW + 2, PH = (TH + 2) * HWD /* 180 */, PHP = 192;
@@ -183,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
 #pragma unroll
   for (int i = 0; i < 2; ++i) load_affine(p.sc1, p.sh1, cb8 + 4 * i, sc1v[i], sh1v[i]);
   // backward: ReLU-mask operands of the phase 1 epilogue, requested before the K loop
-  bf16x8_t mk1[6];
+  bf16x8_t mk1[MB ? 1 : 6];
+  unsigned mw1[MB ? 6 : 1];      // MB: the pixel's 32-channel word of the h2 > 0 bit plane (this lane's byte: fq)
   if constexpr (BWD) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -191,7 +214,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       const int hy = R / HWD, hx = R - hy * HWD;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
-      mk1[j] = (ok && p.m1) ? *(const bf16x8_t*)(p.m1 + (img_pix0 + (int64_t)y * W + x) * C + cb8) : bf16x8_t{};
+      const int64_t pix = img_pix0 + (int64_t)y * W + x;
+      if constexpr (MB) mw1[j] = *(ok ? p.b2 + pix * (C / 32) + wn : (const unsigned*)g_blk_zero);
+      else mk1[j] = (ok && p.m1) ? *(const bf16x8_t*)(p.m1 + pix * C + cb8) : bf16x8_t{};
     }
   }
 
@@ -234,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   BLK_STAMP(3);
 
   bf16x8_t o1v[6];
+  unsigned b1w[6];                // forward: the h1 > 0 word of the pixel (32 channels: this wave's wn)
   unsigned st1 = 0;               // bit j: fragment j of this lane is an interior pixel inside the image -> stored
   {
 #pragma unroll
@@ -246,11 +272,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
 #pragma unroll
       for (int i = 0; i < 2; ++i) v[i] = acc1[i][j] * sc1v[i] + sh1v[i];
       if constexpr (BWD) {
-        if (p.m1) {
+        if (MB || p.m1) {
+          const unsigned m = MB ? (mw1[MB ? j : 0] >> (8 * fq)) : pos_bits8<F16>(mk1[MB ? 0 : j]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[0][e] = (elem_to_f32<F16>(mk1[j][e]) > 0.f) ? v[0][e] : 0.f;
-            v[1][e] = (elem_to_f32<F16>(mk1[j][4 + e]) > 0.f) ? v[1][e] : 0.f;
+            v[0][e] = ((m >> e) & 1u) ? v[0][e] : 0.f;
+            v[1][e] = ((m >> (4 + e)) & 1u) ? v[1][e] : 0.f;
           }
         }
       } else {
@@ -268,6 +295,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + H1_OFF + R * ROWB + (((wn * 4 + fq) ^ ((R >> 1) & 7)) * 16)) = o;
       o1v[j] = o;
       st1 |= (ok && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW) ? (1u << j) : 0u;
+      if constexpr (!BWD) {
+        if (p.b1) b1w[j] = gather_word4(pos_bits8<F16>(o), fq);   // wave-uniform branch: every lane shuffles
+      }
     }
   }
   // b1: H1 complete (LDS writes of every wave), taps 2..6 landed (taps 0 / 1 long ago)
@@ -279,16 +309,24 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     if ((st1 >> j) & 1u) {
       const int R = wm * 96 + j * 16 + fr;
       const int hy = R / HWD, hx = R - hy * HWD;
-      *(bf16x8_t*)(p.o1 + (img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx)) * C + cb8) = o1v[j];
+      const int64_t pix = img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx);
+      *(bf16x8_t*)(p.o1 + pix * C + cb8) = o1v[j];
+      if constexpr (!BWD) {
+        if (p.b1 && fq == 0) p.b1[pix * (C / 32) + wn] = b1w[j];
+      }
     }
   }
   // backward: mask operands of the phase 2 epilogue
-  bf16x8_t mk2[4];
+  bf16x8_t mk2[MB ? 1 : 4];
+  unsigned mw2[MB ? 4 : 1];
   if constexpr (BWD) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int y = y0 + wm * 4 + j, x = x0 + pi;
-      mk2[j] = (p.m2 && y < H && x < W) ? *(const bf16x8_t*)(p.m2 + (img_pix0 + (int64_t)y * W + x) * C + cb8) : bf16x8_t{};
+      const bool ok = (y < H) && (x < W);
+      const int64_t pix = img_pix0 + (int64_t)y * W + x;
+      if constexpr (MB) mw2[j] = *(ok ? p.b1 + pix * (C / 32) + wn : (const unsigned*)g_blk_zero);
+      else mk2[j] = (p.m2 && ok) ? *(const bf16x8_t*)(p.m2 + pix * C + cb8) : bf16x8_t{};
     }
   }
 
@@ -299,33 +337,46 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   const int chw = wn * 64 + fq * 16;       // + nc * 128: this lane's 16 consecutive output channels
   // Loads and stores of output pixels outside the image (ragged tiles) are redirected to the zero page / a sink line
   // instead of being branched around: see g_blk_sink.
-  const bf16_t* adp[4];
-  const bf16_t* mkp[4];
-  bf16_t* o3p[4];
+  // Only the pixel index is kept per output pixel (-1: outside the image); operand / result addresses are formed where
+  // they are used (one 64-bit multiply-add each).  Invalid pixels read the zero page and write a sink line.
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  int pixj[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int y = y0 + wm * 4 + j, x = x0 + fr;
-    const bool ok = (y < H) && (x < W);
-    const int64_t off = (img_pix0 + (int64_t)y * W + x) * C4 + chw;
-    adp[j] = ok ? p.a + off : (const bf16_t*)g_blk_zero;
-    mkp[j] = (ok && p.m3) ? p.m3 + off : (const bf16_t*)g_blk_zero;
-    o3p[j] = ok ? p.o3 + off : (bf16_t*)g_blk_sink;
+    pixj[j] = ((y < H) && (x < W)) ? (int)(img_pix0 + (int64_t)y * W + x) : -1;
   }
-  bf16x8_t ad0[4][2], ad1[4][2], mk3[4][2];
+  auto adp = [&](int j) { return pixj[j] >= 0 ? p.a + (int64_t)pixj[j] * C4 + chw : (const bf16_t*)g_blk_zero; };
+  auto mkp = [&](int j) { return (pixj[j] >= 0 && p.m3 && !MB) ? p.m3 + (int64_t)pixj[j] * C4 + chw : (const bf16_t*)g_blk_zero; };
+  auto o3p = [&](int j) { return pixj[j] >= 0 ? p.o3 + (int64_t)pixj[j] * C4 + chw : (bf16_t*)g_blk_sink; };
+  // MB: this lane's pair of words (64 channels: wn) of the x > 0 plane, + nc * (C / 16); forward: lane fq == 0 stores it
+  auto b3r = [&](int j) { return (pixj[j] >= 0 && MB) ? p.b3 + (int64_t)pixj[j] * (C4 / 32) + wn * 2 : (const unsigned*)g_blk_zero; };
+  auto b3w = [&](int j) { return (pixj[j] >= 0 && !BWD && p.b3 && fq == 0) ? p.b3 + (int64_t)pixj[j] * (C4 / 32) + wn * 2 : (unsigned*)g_blk_sink; };
+  bf16x8_t ad0[4][2], ad1[4][2], mk3[MB ? 1 : 4][2];
+  u32x2_t mw3[MB ? 2 : 1][4];    // MB: both passes' word pairs
   auto load_ad = [&](int nc, bf16x8_t (&dst)[4][2]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) dst[j][h] = *(const bf16x8_t*)(adp[j] + nc * 128 + h * 8);
+      for (int h = 0; h < 2; ++h) dst[j][h] = *(const bf16x8_t*)(adp(j) + nc * 128 + h * 8);
   };
   auto load_mask3 = [&](int nc) {
+    if constexpr (!MB) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) mk3[j][h] = *(const bf16x8_t*)(mkp[j] + nc * 128 + h * 8);
+        for (int h = 0; h < 2; ++h) mk3[j][h] = *(const bf16x8_t*)(mkp(j) + nc * 128 + h * 8);
+    }
   };
   load_ad(0, ad0);
-  if constexpr (BWD) load_mask3(0); else load_ad(1, ad1);
+  if constexpr (BWD && !MB) load_mask3(0);
+  else load_ad(1, ad1);      // forward, and backward with bit planes (8 B of mask per pixel instead of 32 B per pass)
+  if constexpr (MB) {
+#pragma unroll
+    for (int nc = 0; nc < 2; ++nc)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mw3[nc][j] = *(const u32x2_t*)(b3r(j) + nc * (C / 16));
+  }
 
   // ================= phase 2: H2[8x16][C] =================
   f32x4_t acc2[2][4];
@@ -378,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   lds_barrier();   // b4: every wave is done with H1
   BLK_STAMP(7);
   bf16x8_t o2v[4];
+  unsigned b2w[4];
   f32x4_t sc3v[4], sh3v[4];
   {
 #pragma unroll
@@ -386,11 +438,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
 #pragma unroll
       for (int i = 0; i < 2; ++i) v[i] = acc2[i][j] * sc2v[i] + sh2v[i];
       if constexpr (BWD) {
-        if (p.m2) {
+        if (MB || p.m2) {
+          const unsigned m = MB ? (mw2[MB ? j : 0] >> (8 * fq)) : pos_bits8<F16>(mk2[MB ? 0 : j]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[0][e] = (elem_to_f32<F16>(mk2[j][e]) > 0.f) ? v[0][e] : 0.f;
-            v[1][e] = (elem_to_f32<F16>(mk2[j][4 + e]) > 0.f) ? v[1][e] : 0.f;
+            v[0][e] = ((m >> e) & 1u) ? v[0][e] : 0.f;
+            v[1][e] = ((m >> (4 + e)) & 1u) ? v[1][e] : 0.f;
           }
         }
       } else {
@@ -408,6 +461,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       const int pr = (wm * 4 + j) * TW + pi;
       *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + H2_OFF + pr * ROWB + (((wn * 4 + fq) ^ ((pr >> 1) & 7)) * 16)) = o;
       o2v[j] = o;
+      if constexpr (!BWD) {
+        if (p.b2) b2w[j] = gather_word4(pos_bits8<F16>(o), fq);
+      }
     }
   }
 #pragma unroll
@@ -454,13 +510,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
             v[2 * h + 1][e] += elem_to_f32<F16>((nc == 0 ? ad0 : ad1)[j][h][4 + e]);
           }
         if constexpr (BWD) {
-          const bool has_m3 = p.m3 != nullptr;   // no mask: the select below keeps every value
+          // this lane's 16 mask bits of the pixel (bit 8h + e: element e of half h); no mask at all: all ones
+          unsigned m;
+          if constexpr (MB) m = ((fq & 2) ? mw3[MB ? nc : 0][j][1] : mw3[MB ? nc : 0][j][0]) >> (16 * (fq & 1));
+          else m = p.m3 ? (pos_bits8<F16>(mk3[MB ? 0 : j][0]) | (pos_bits8<F16>(mk3[MB ? 0 : j][1]) << 8)) : 0xffffu;
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              v[2 * h][e] = (!has_m3 || elem_to_f32<F16>(mk3[j][h][e]) > 0.f) ? v[2 * h][e] : 0.f;
-              v[2 * h + 1][e] = (!has_m3 || elem_to_f32<F16>(mk3[j][h][4 + e]) > 0.f) ? v[2 * h + 1][e] : 0.f;
+              v[2 * h][e] = ((m >> (8 * h + e)) & 1u) ? v[2 * h][e] : 0.f;
+              v[2 * h + 1][e] = ((m >> (8 * h + 4 + e)) & 1u) ? v[2 * h + 1][e] : 0.f;
             }
         } else {
 #pragma unroll
@@ -479,20 +538,34 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       BLK_STAMP(9 + nc);
       __builtin_amdgcn_sched_barrier(0);
       if (nc == 0) {   // the second pass's operands travel while the first pass's results are stored
-        if constexpr (BWD) { load_ad(1, ad1); load_mask3(1); }
+        if constexpr (BWD && !MB) { load_ad(1, ad1); load_mask3(1); }
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, 128 + chw + 4 * i, sc3v[i], sh3v[i]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {   // h2 / g1 to HBM: behind every load a later wait counts
           const int y = y0 + wm * 4 + j, x = x0 + pi;
-          bf16_t* dst = (y < H && x < W) ? p.o2 + (img_pix0 + (int64_t)y * W + x) * C + cb8 : (bf16_t*)g_blk_sink;
-          *(bf16x8_t*)dst = o2v[j];
+          const bool ok = (y < H) && (x < W);
+          const int64_t pix = img_pix0 + (int64_t)y * W + x;
+          *(bf16x8_t*)(ok ? p.o2 + pix * C + cb8 : (bf16_t*)g_blk_sink) = o2v[j];
+          if constexpr (!BWD) {
+            if (p.b2) *((ok && fq == 0) ? p.b2 + pix * (C / 32) + wn : (unsigned*)g_blk_sink) = b2w[j];
+          }
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) *(bf16x8_t*)(o3p[j] + nc * 128 + h * 8) = ov[j][h];
+        for (int h = 0; h < 2; ++h) *(bf16x8_t*)(o3p(j) + nc * 128 + h * 8) = ov[j][h];
+        if constexpr (!BWD) {
+          if (p.b3) {   // x > 0 of this lane's 16 channels -> the pixel's 64-channel word pair, stored by lane fq == 0
+            const bf16x8_t (&ad)[4][2] = nc == 0 ? ad0 : ad1;
+            unsigned v16 = (pos_bits8<F16>(ad[j][0]) | (pos_bits8<F16>(ad[j][1]) << 8)) << (16 * (fq & 1));
+            v16 |= __shfl_xor(v16, 16);
+            const unsigned other = __shfl_xor(v16, 32);
+            *(u32x2_t*)(b3w(j) + nc * (C / 16)) = (u32x2_t){v16, other};
+          }
+        }
+      }
     }
   }
 #ifdef TDN_TRACE_BUILD
@@ -525,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
 // the eight lanes of a ds_read_b128 lane group that share a k-chunk see eight consecutive values of R >> 1, and the
 // two k-chunks of a group differ in bit 0, which f leaves alone.
 // ---------------------------------------------------------------------------------------------
-template <bool BWD, bool F16>
+template <bool BWD, bool F16, bool MB = false>
 __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int C = 128, C4 = 512, TH = 8, TW = 16, HWD = TW + 2, PH = (TH + 2) * HWD /* 180 */, PHP = 192;
@@ -624,7 +697,8 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
   f32x4_t sc1v[2], sh1v[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) load_affine(p.sc1, p.sh1, cb8 + 4 * i, sc1v[i], sh1v[i]);
-  bf16x8_t mk1[6];
+  bf16x8_t mk1[MB ? 1 : 6];
+  unsigned mw1[MB ? 6 : 1];      // MB: the pixel's 32-channel word of the h2 > 0 bit plane (this lane's byte: fq)
   if constexpr (BWD) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -632,7 +706,9 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
       const int hy = R / HWD, hx = R - hy * HWD;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
-      mk1[j] = *(const bf16x8_t*)((ok && p.m1) ? p.m1 + (img_pix0 + (int64_t)y * W + x) * C + cb8 : (const bf16_t*)g_blk_zero);
+      const int64_t pix = img_pix0 + (int64_t)y * W + x;
+      if constexpr (MB) mw1[j] = *(ok ? p.b2 + pix * (C / 32) + wn : (const unsigned*)g_blk_zero);
+      else mk1[j] = *(const bf16x8_t*)((ok && p.m1) ? p.m1 + pix * C + cb8 : (const bf16_t*)g_blk_zero);
     }
   }
 
@@ -673,17 +749,21 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
   // waits of the unit stream only ever find them OLDER than the units they may leave in flight (a count that is too
   // small over-waits; one that is too large would let a unit be read before it has landed): the phase 2 mask loads and
   // the h1 / g2 stores go in front of units 5 and 6.
-  bf16x8_t mk2[4];
+  bf16x8_t mk2[MB ? 1 : 4];
+  unsigned mw2[MB ? 4 : 1];
   if constexpr (BWD) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int y = y0 + wm * 4 + j, x = x0 + pi;
-      mk2[j] = *(const bf16x8_t*)((p.m2 && y < H && x < W) ? p.m2 + (img_pix0 + (int64_t)y * W + x) * C + cb8
-                                                             : (const bf16_t*)g_blk_zero);
+      const bool ok = (y < H) && (x < W);
+      const int64_t pix = img_pix0 + (int64_t)y * W + x;
+      if constexpr (MB) mw2[j] = *(ok ? p.b1 + pix * (C / 32) + wn : (const unsigned*)g_blk_zero);
+      else mk2[j] = *(const bf16x8_t*)((p.m2 && ok) ? p.m2 + pix * C + cb8 : (const bf16_t*)g_blk_zero);
     }
   }
 
   bf16x8_t o1v[6];
+  unsigned b1w[6];
   unsigned st1 = 0;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -695,11 +775,12 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
 #pragma unroll
     for (int i = 0; i < 2; ++i) v[i] = acc1[i][j] * sc1v[i] + sh1v[i];
     if constexpr (BWD) {
-      if (p.m1) {
+      if (MB || p.m1) {
+        const unsigned m = MB ? (mw1[MB ? j : 0] >> (8 * fq)) : pos_bits8<F16>(mk1[MB ? 0 : j]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[0][e] = (elem_to_f32<F16>(mk1[j][e]) > 0.f) ? v[0][e] : 0.f;
-          v[1][e] = (elem_to_f32<F16>(mk1[j][4 + e]) > 0.f) ? v[1][e] : 0.f;
+          v[0][e] = ((m >> e) & 1u) ? v[0][e] : 0.f;
+          v[1][e] = ((m >> (4 + e)) & 1u) ? v[1][e] : 0.f;
         }
       }
     } else {
@@ -717,13 +798,20 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
     *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + R * RB + (((wn * 4 + fq) ^ f256(R)) * 16)) = o;
     o1v[j] = o;
     st1 |= (ok && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW) ? (1u << j) : 0u;
+    if constexpr (!BWD) {
+      if (p.b1) b1w[j] = gather_word4(pos_bits8<F16>(o), fq);   // wave-uniform branch: every lane shuffles
+    }
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {   // h1 / g2 to HBM
     if ((st1 >> j) & 1u) {
       const int R = wm * 96 + j * 16 + fr;
       const int hy = R / HWD, hx = R - hy * HWD;
-      *(bf16x8_t*)(p.o1 + (img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx)) * C + cb8) = o1v[j];
+      const int64_t pix = img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx);
+      *(bf16x8_t*)(p.o1 + pix * C + cb8) = o1v[j];
+      if constexpr (!BWD) {
+        if (p.b1 && fq == 0) p.b1[pix * (C / 32) + wn] = b1w[j];
+      }
     }
   }
   load_unit(5);
@@ -737,31 +825,37 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
     for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // phase 3 operand addresses (dealt pixel pi of tile row wm * 4 + j)
   const int chw = wn * 64 + fq * 16;       // + nc * 256
-  const bf16_t* adp[4];
-  const bf16_t* mkp[4];
-  bf16_t* o3p[4];
-  bf16_t* o2p[4];
+  // Only the pixel index is kept per output pixel (-1: outside the image); the operand / result addresses are formed
+  // where they are used (one 64-bit multiply-add each) — seven pointer sets cost 56 registers this kernel does not have.
+  // Invalid pixels read the zero page and write a sink line (no branches: see g_blk_sink).
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  int pixj[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int y = y0 + wm * 4 + j, x = x0 + pi;
-    const bool ok = (y < H) && (x < W);
-    const int64_t pix = img_pix0 + (int64_t)y * W + x;
-    adp[j] = ok ? p.a + pix * C4 + chw : (const bf16_t*)g_blk_zero;
-    mkp[j] = (ok && p.m3) ? p.m3 + pix * C4 + chw : (const bf16_t*)g_blk_zero;
-    o3p[j] = ok ? p.o3 + pix * C4 + chw : (bf16_t*)g_blk_sink;
-    o2p[j] = ok ? p.o2 + pix * C + cb8 : (bf16_t*)g_blk_sink;
+    pixj[j] = ((y < H) && (x < W)) ? (int)(img_pix0 + (int64_t)y * W + x) : -1;
   }
+  auto adp = [&](int j) { return pixj[j] >= 0 ? p.a + (int64_t)pixj[j] * C4 + chw : (const bf16_t*)g_blk_zero; };
+  auto mkp = [&](int j) { return (pixj[j] >= 0 && p.m3 && !MB) ? p.m3 + (int64_t)pixj[j] * C4 + chw : (const bf16_t*)g_blk_zero; };
+  auto o3p = [&](int j) { return pixj[j] >= 0 ? p.o3 + (int64_t)pixj[j] * C4 + chw : (bf16_t*)g_blk_sink; };
+  auto o2p = [&](int j) { return pixj[j] >= 0 ? p.o2 + (int64_t)pixj[j] * C + cb8 : (bf16_t*)g_blk_sink; };
+  auto b3r = [&](int j) { return (pixj[j] >= 0 && MB) ? p.b3 + (int64_t)pixj[j] * (C4 / 32) + wn * 2 : (const unsigned*)g_blk_zero; };
+  auto b3w = [&](int j) { return (pixj[j] >= 0 && !BWD && p.b3 && fq == 0) ? p.b3 + (int64_t)pixj[j] * (C4 / 32) + wn * 2 : (unsigned*)g_blk_sink; };
+  auto b2p = [&](int j) { return (pixj[j] >= 0 && !BWD && p.b2 && fq == 0) ? p.b2 + (int64_t)pixj[j] * (C / 32) + wn : (unsigned*)g_blk_sink; };
   // Phase 3's per-pixel operands (addend, ReLU-mask source).  Loads return in issue order, so a load issued behind a
   // batch of LDS-DMA units is not back before those have landed: the first pass's operands are requested in the middle
   // of phase 2 (8 or 16 unconditional loads, accounted for in the counted waits of the six iterations in which they
   // are younger than the awaited unit), the second pass's addend right behind phase 2.
-  bf16x8_t ad0[4][2], ad1[4][2], mk3[4][2];
-  constexpr int NADD = BWD ? 16 : 8;
+  bf16x8_t ad0[4][2], ad1[4][2], mk3[MB ? 1 : 4][2];
+  u32x2_t mw3[MB ? 2 : 1][4];    // MB: both passes' word pairs
+  constexpr int NADD = BWD ? 16 : 8;   // loads issued at u == 9: 8 addend + (backward) 8 mask values or 8 word pairs
   auto load_mask3 = [&](int nc) {
+    if constexpr (!MB) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) mk3[j][h] = *(const bf16x8_t*)(mkp[j] + nc * 256 + h * 8);
+        for (int h = 0; h < 2; ++h) mk3[j][h] = *(const bf16x8_t*)(mkp(j) + nc * 256 + h * 8);
+    }
   };
 #pragma unroll
   for (int u = 0; u < 18; ++u) {
@@ -775,8 +869,14 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) ad0[j][h] = *(const bf16x8_t*)(adp[j] + h * 8);
-      if constexpr (BWD) load_mask3(0);
+        for (int h = 0; h < 2; ++h) ad0[j][h] = *(const bf16x8_t*)(adp(j) + h * 8);
+      if constexpr (BWD && !MB) load_mask3(0);
+      if constexpr (MB) {
+#pragma unroll
+        for (int nc = 0; nc < 2; ++nc)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mw3[nc][j] = *(const u32x2_t*)(b3r(j) + nc * (C / 16));
+      }
     }
     if (u == 0) BLK_STAMP(4);
     if (u == 9) BLK_STAMP(5);
@@ -809,13 +909,12 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) ad1[j][h] = *(const bf16x8_t*)(adp[j] + 256 + h * 8);
+      for (int h = 0; h < 2; ++h) ad1[j][h] = *(const bf16x8_t*)(adp(j) + 256 + h * 8);
   };
   if constexpr (!BWD) load_ad1();
   f32x4_t sc3v[4], sh3v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, chw + 4 * i, sc3v[i], sh3v[i]);
-  bf16x8_t o2v[4];
   {
     f32x4_t sc2v[2], sh2v[2];
 #pragma unroll
@@ -828,11 +927,12 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
 #pragma unroll
       for (int i = 0; i < 2; ++i) v[i] = acc2[i][j] * sc2v[i] + sh2v[i];
       if constexpr (BWD) {
-        if (p.m2) {
+        if (MB || p.m2) {
+          const unsigned m = MB ? (mw2[MB ? j : 0] >> (8 * fq)) : pos_bits8<F16>(mk2[MB ? 0 : j]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[0][e] = (elem_to_f32<F16>(mk2[j][e]) > 0.f) ? v[0][e] : 0.f;
-            v[1][e] = (elem_to_f32<F16>(mk2[j][4 + e]) > 0.f) ? v[1][e] : 0.f;
+            v[0][e] = ((m >> e) & 1u) ? v[0][e] : 0.f;
+            v[1][e] = ((m >> (4 + e)) & 1u) ? v[1][e] : 0.f;
           }
         }
       } else {
@@ -849,12 +949,15 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
       }
       const int pr = (wm * 4 + j) * TW + pi;
       *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + pr * RB + (((wn * 4 + fq) ^ f256(pr)) * 16)) = o;
-      o2v[j] = o;
+      *(bf16x8_t*)o2p(j) = o;           // h2 / g1 to HBM (sink line for pixels outside the image)
+      if constexpr (!BWD) {
+        if (p.b2) *b2p(j) = gather_word4(pos_bits8<F16>(o), fq);
+      }
     }
   }
-  // b5: H2 complete; conv3 units 18..21 landed (22..24 may still travel; compiler-visible loads in between only make
-  // the counted wait stricter)
-  asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // b5: H2 complete; conv3 units 18..21 landed.  Younger than unit 21 in this wave's queue: units 22..24 (6 LDS-DMA)
+  // and the 4 unconditional h2 / g1 stores above (the forward's bit-plane words, if any, only make the wait stricter)
+  asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   BLK_STAMP(8);
 
   // ================= phase 3: two passes of 256 channels =================
@@ -904,13 +1007,15 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
           v[2 * h + 1][e] += elem_to_f32<F16>((nc == 0 ? ad0 : ad1)[j][h][4 + e]);
         }
       if constexpr (BWD) {
-        const bool has_m3 = p.m3 != nullptr;
+        unsigned m;
+        if constexpr (MB) m = ((fq & 2) ? mw3[MB ? nc : 0][j][1] : mw3[MB ? nc : 0][j][0]) >> (16 * (fq & 1));
+        else m = p.m3 ? (pos_bits8<F16>(mk3[MB ? 0 : j][0]) | (pos_bits8<F16>(mk3[MB ? 0 : j][1]) << 8)) : 0xffffu;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[2 * h][e] = (!has_m3 || elem_to_f32<F16>(mk3[j][h][e]) > 0.f) ? v[2 * h][e] : 0.f;
-            v[2 * h + 1][e] = (!has_m3 || elem_to_f32<F16>(mk3[j][h][4 + e]) > 0.f) ? v[2 * h + 1][e] : 0.f;
+            v[2 * h][e] = ((m >> (8 * h + e)) & 1u) ? v[2 * h][e] : 0.f;
+            v[2 * h + 1][e] = ((m >> (8 * h + 4 + e)) & 1u) ? v[2 * h + 1][e] : 0.f;
           }
       } else {
 #pragma unroll
@@ -925,6 +1030,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
           ov[j][h][e] = f32_to_elem<F16>(v[2 * h][e]);
           ov[j][h][4 + e] = f32_to_elem<F16>(v[2 * h + 1][e]);
         }
+      __builtin_amdgcn_sched_barrier(0);   // one pixel at a time: interleaving the four keeps 4 x 16 fp32 temporaries live
     }
     BLK_STAMP(9 + nc);
     __builtin_amdgcn_sched_barrier(0);
@@ -932,16 +1038,25 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
       if constexpr (BWD) { load_ad1(); load_mask3(1); }
 #pragma unroll
       for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, 256 + chw + 4 * i, sc3v[i], sh3v[i]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) *(bf16x8_t*)o2p[j] = o2v[j];     // h2 / g1
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) *(bf16x8_t*)(o3p[j] + nc * 256 + h * 8) = ov[j][h];
-    // b7: units 22..25 landed.  Behind unit 25 this wave has issued 8 + 8 addend and mask loads (backward) or up to 8
-    // affine loads (forward: none if there is no BN), then 4 + 8 stores — all unconditional (sink / zero-page redirect)
-    if (nc == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(BWD ? 28 : 12) : "memory");
+      for (int h = 0; h < 2; ++h) *(bf16x8_t*)(o3p(j) + nc * 256 + h * 8) = ov[j][h];
+      if constexpr (!BWD) {
+        if (p.b3) {   // x > 0 of this lane's 16 channels -> the pixel's 64-channel word pair, stored by lane fq == 0
+          const bf16x8_t (&ad)[4][2] = nc == 0 ? ad0 : ad1;
+          unsigned v16 = (pos_bits8<F16>(ad[j][0]) | (pos_bits8<F16>(ad[j][1]) << 8)) << (16 * (fq & 1));
+          v16 |= __shfl_xor(v16, 16);
+          const unsigned other = __shfl_xor(v16, 32);
+          *(u32x2_t*)(b3w(j) + nc * (C / 16)) = (u32x2_t){v16, other};
+        }
+      }
+    }
+    // b7: units 22..25 landed.  Behind unit 25 this wave has issued 8 + 8 addend and mask loads (backward without bit
+    // planes) or up to 8 affine loads (forward: none if there is no BN), then the pass's 8 stores — all unconditional
+    // (sink / zero-page redirect); bit-plane words, if any, only make the wait stricter
+    if (nc == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(BWD ? (MB ? 16 : 24) : 8) : "memory");
   }
 #ifdef TDN_TRACE_BUILD
   BLK_STAMP(11);
@@ -954,22 +1069,22 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-template <bool BWD, bool F16>
+template <bool BWD, bool F16, bool MB = false>
 static int launch_block64(BlockParams& p, hipStream_t stream) {
   constexpr int lds = 81920;
   static tdn_attr_once attr_once;
   if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute((const void*)bottleneck64_kernel<BWD, F16>,
+    hipError_t e = hipFuncSetAttribute((const void*)bottleneck64_kernel<BWD, F16, MB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
     attr_once.mark();
     if (getenv("TDN_DEBUG_OCC")) {
       int nb = -1;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bottleneck64_kernel<BWD, F16>, 256, lds);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bottleneck64_kernel<BWD, F16, MB>, 256, lds);
       fprintf(stderr, "[tdn] bottleneck64<%d,%d>: %d B LDS, %d workgroups/CU\n", (int)BWD, (int)F16, lds, nb);
     }
   }
-  TDN_LAUNCH((bottleneck64_kernel<BWD, F16>), dim3(p.nwg_pad), dim3(256), lds, stream, p);
+  TDN_LAUNCH((bottleneck64_kernel<BWD, F16, MB>), dim3(p.nwg_pad), dim3(256), lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -979,17 +1094,17 @@ static unsigned long long* g_blk_trace = nullptr;
 extern "C" int tdn_debug_block_trace(void* buf) { g_blk_trace = (unsigned long long*)buf; return 0; }   // >= 128 B per workgroup
 #endif
 
-template <bool BWD, bool F16>
+template <bool BWD, bool F16, bool MB = false>
 static int launch_block128(BlockParams& p, hipStream_t stream) {
   constexpr int lds = 163840;
   static tdn_attr_once attr_once;
   if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute((const void*)bottleneck128_kernel<BWD, F16>,
+    hipError_t e = hipFuncSetAttribute((const void*)bottleneck128_kernel<BWD, F16, MB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
     attr_once.mark();
   }
-  TDN_LAUNCH((bottleneck128_kernel<BWD, F16>), dim3(p.nwg_pad), dim3(512), lds, stream, p);
+  TDN_LAUNCH((bottleneck128_kernel<BWD, F16, MB>), dim3(p.nwg_pad), dim3(512), lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -1022,6 +1137,7 @@ extern "C" int tdn_bottleneck_fwd(const tdn_bottleneck_args* a, int dtype, void*
   BlockParams p;
   if (block_common(p, a, dtype)) return -1;
   p.sc1 = a->scale1; p.sh1 = a->shift1; p.sc2 = a->scale2; p.sh2 = a->shift2; p.sc3 = a->scale3; p.sh3 = a->shift3;
+  p.b1 = (unsigned*)a->bits1; p.b2 = (unsigned*)a->bits2; p.b3 = (unsigned*)a->bits3;   // optional outputs
   if (a->C == 128) {
     if (dtype == TDN_F16) return launch_block128<false, true>(p, (hipStream_t)stream);
     return launch_block128<false, false>(p, (hipStream_t)stream);
@@ -1034,6 +1150,17 @@ extern "C" int tdn_bottleneck_dgrad(const tdn_bottleneck_args* a, int dtype, voi
   BlockParams p;
   if (block_common(p, a, dtype)) return -1;
   p.m1 = (const bf16_t*)a->mask1; p.m2 = (const bf16_t*)a->mask2; p.m3 = (const bf16_t*)a->mask3;
+  p.b1 = (unsigned*)a->bits1; p.b2 = (unsigned*)a->bits2; p.b3 = (unsigned*)a->bits3;
+  const bool mb = a->bits1 || a->bits2 || a->bits3;
+  if (mb) {
+    TDN_CHECK(a->bits1 && a->bits2 && a->bits3, "bottleneck dgrad: all three bit planes or none");
+    if (a->C == 128) {
+      if (dtype == TDN_F16) return launch_block128<true, true, true>(p, (hipStream_t)stream);
+      return launch_block128<true, false, true>(p, (hipStream_t)stream);
+    }
+    if (dtype == TDN_F16) return launch_block64<true, true, true>(p, (hipStream_t)stream);
+    return launch_block64<true, false, true>(p, (hipStream_t)stream);
+  }
   if (a->C == 128) {
     if (dtype == TDN_F16) return launch_block128<true, true>(p, (hipStream_t)stream);
     return launch_block128<true, false>(p, (hipStream_t)stream);

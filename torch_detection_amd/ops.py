@@ -264,7 +264,14 @@ def bottleneck_supported(H, W, C, stride=1, dilation=1):
     return bool(_lib.load().tdn_bottleneck_supported(int(H), int(W), int(C), int(stride), int(dilation)))
 
 
-def _bottleneck_args(name, a, w1, w2, w3, affine, masks, outs):
+def bottleneck_bit_planes(N, H, W, C, device):
+    """Empty ReLU bit planes of one bottleneck (1 bit per element; include/tdn.h: tdn_bottleneck_args.bits1..3):
+    (h1 > 0, h2 > 0) of C channels and (x > 0) of 4C channels, as int32 words [N][H][W][channels / 32]."""
+    mk = lambda ch: torch.empty(N, H, W, ch // 32, dtype=torch.int32, device=device)
+    return mk(C), mk(C), mk(4 * C)
+
+
+def _bottleneck_args(name, a, w1, w2, w3, affine, masks, outs, bits=None):
     _chk_act(a, "in")
     N, H, W, C4 = a.shape
     C = C4 // 4
@@ -296,26 +303,38 @@ def _bottleneck_args(name, a, w1, w2, w3, affine, masks, outs):
                 setattr(args, fld, m.data_ptr())
     args.out1, args.out2, args.out3 = o1.data_ptr(), o2.data_ptr(), o3.data_ptr()
     args.N, args.H, args.W, args.C = N, H, W, C
+    if bits is not None:
+        for fld, b, ch in zip(("bits1", "bits2", "bits3"), bits, (C, C, C4)):
+            if b is None:
+                continue
+            if b.dtype != torch.int32 or tuple(b.shape) != (N, H, W, ch // 32) or not b.is_contiguous() or not b.is_cuda:
+                raise ValueError("%s: %s must be a contiguous CUDA int32 tensor of shape %s, got %s %s" %
+                                 (name, fld, (N, H, W, ch // 32), b.dtype, tuple(b.shape)))
+            setattr(args, fld, b.data_ptr())
     return args, (o1, o2, o3)
 
 
-def bottleneck_fwd(x, w1, w2, w3, affine, outs=None):
+def bottleneck_fwd(x, w1, w2, w3, affine, outs=None, bits=None):
     """Stride-1 Bottleneck (resnet.py:97-119) in one launch: returns (h1, h2, out).  ``affine`` = (scale1, shift1,
-    scale2, shift2, scale3, shift3) of the folded BNs; w_k = w_fwd packs of conv1 / conv2 / conv3."""
-    args, o = _bottleneck_args("bottleneck_fwd", x, w1, w2, w3, affine, None, outs)
+    scale2, shift2, scale3, shift3) of the folded BNs; w_k = w_fwd packs of conv1 / conv2 / conv3.  ``bits`` = optional
+    (b1, b2, b3) from ``bottleneck_bit_planes``: the kernel also writes h1 > 0, h2 > 0 and x > 0 as bit planes — the
+    backward call reads those instead of the 16-bit tensors."""
+    args, o = _bottleneck_args("bottleneck_fwd", x, w1, w2, w3, affine, None, outs, bits)
     _lib.check(_lib.load().tdn_bottleneck_fwd(ctypes.byref(args), dtype_code(x.dtype), _lib.stream_ptr()),
                "tdn_bottleneck_fwd")
     return o
 
 
-def bottleneck_dgrad(g, w3d, w2d, w1d, masks, outs=None):
+def bottleneck_dgrad(g, w3d, w2d, w1d, masks, outs=None, bits=None):
     """Input-gradient chain of the same block in one launch: returns (g2, g1, dx) with g2 = mask(h2) . conv3^T(g),
     g1 = mask(h1) . conv2^T(g2), dx = mask(x) . (conv1^T(g1) + g).  ``masks`` = (h2, h1, x | None); w_kd = w_dgrad packs
-    of conv3 / conv2 / conv1."""
+    of conv3 / conv2 / conv1.  ``bits`` = the (b1, b2, b3) bit planes the forward call wrote: used INSTEAD of ``masks``."""
     C = g.shape[3] // 4
     if tuple(w3d.shape) != (C, 1, 1, 4 * C) or tuple(w1d.shape) != (4 * C, 1, 1, C):
         raise ValueError("bottleneck_dgrad: w_dgrad packs have shapes %s / %s" % (tuple(w3d.shape), tuple(w1d.shape)))
-    args, o = _bottleneck_args("bottleneck_dgrad", g, w3d, w2d, w1d, None, masks, outs)
+    if bits is not None and any(b is None for b in bits):
+        raise ValueError("bottleneck_dgrad: all three bit planes or none")
+    args, o = _bottleneck_args("bottleneck_dgrad", g, w3d, w2d, w1d, None, None if bits is not None else masks, outs, bits)
     _lib.check(_lib.load().tdn_bottleneck_dgrad(ctypes.byref(args), dtype_code(g.dtype), _lib.stream_ptr()),
                "tdn_bottleneck_dgrad")
     return o
