@@ -80,13 +80,27 @@ struct BlockParams {
 static __device__ __attribute__((aligned(256))) unsigned char g_blk_sink[512];
 static __device__ __attribute__((aligned(256))) unsigned char g_blk_zero[512];   // load source of such pixels (a lane reads up to 288 B behind its base)
 
-// bit e of the result: element e of v is > 0 (what the ReLU masks of the backward pass test)
+// bit e of the result: element e of v is > 0 (what the ReLU masks of the backward pass test).  Both 16-bit float formats
+// are sign-magnitude, so "> 0" is the signed 16-bit integer test: max(min(h, 1), 0) is 1 for a positive half-word and 0
+// otherwise — two packed 16-bit instructions per pair of elements instead of convert + compare + select + or per
+// element (the plane costs the forward launch ~10 % otherwise).  A positive NaN counts as positive here; a float
+// compare would say no — ReLU outputs are never NaN.
 template <bool F16>
 __device__ __forceinline__ unsigned pos_bits8(bf16x8_t v) {
-  unsigned m = 0;
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4v_t __attribute__((ext_vector_type(4)));
+  const u32x4v_t w = __builtin_bit_cast(u32x4v_t, v);
+  unsigned f[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) m |= (elem_to_f32<F16>(v[e]) > 0.f) ? (1u << e) : 0u;
-  return m;
+  for (int i = 0; i < 4; ++i) {
+    const unsigned wi = w[i];     // (a bit_cast of the vector ELEMENT expression itself miscompiles: clang 19, host and device)
+    const s16x2_t one = {1, 1}, zero = {0, 0};
+    s16x2_t h = __builtin_bit_cast(s16x2_t, wi);
+    h = __builtin_elementwise_max(__builtin_elementwise_min(h, one), zero);
+    f[i] = __builtin_bit_cast(unsigned, h);          // bit 0: element 2i, bit 16: element 2i + 1
+  }
+  const unsigned r = f[0] | (f[1] << 2) | (f[2] << 4) | (f[3] << 6);   // element 2i at bit 2i, element 2i + 1 at bit 16 + 2i
+  return (r | (r >> 15)) & 0xffu;
 }
 // the four lanes fr, fr + 16, fr + 32, fr + 48 (fq = 0..3) each hold one byte of a pixel's 32-channel word: every lane
 // gets the whole word
@@ -195,6 +209,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   const int pi = fr < 4 ? 2 * fr : (fr >= 12 ? 2 * (fr - 8) : 2 * (fr - 4) + 1);
   const int cb8 = wn * 32 + fq * 8;     // this lane's 8 consecutive channels of the C-wide outputs
 
+  // pick element fq of a 4-entry register array (every lane holds all entries after the gathers): lets the four lanes
+  // of a pixel column store four different fragments' words with ONE instruction instead of one lane storing four times
+  auto sel4 = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3) { return fq == 0 ? a0 : (fq == 1 ? a1 : (fq == 2 ? a2 : a3)); };
   // per-channel affine of an epilogue: folded BN in the forward pass (NULL: 1 / 0); the backward pass has none — the
   // same fma(acc, 1, 0) as conv_gemm_kernel computes for a NULL scale / shift, with constant operands
   auto load_affine = [&](const float* scp, const float* shp, int ch, f32x4_t& sc, f32x4_t& sh) {
@@ -311,8 +328,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       const int hy = R / HWD, hx = R - hy * HWD;
       const int64_t pix = img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx);
       *(bf16x8_t*)(p.o1 + pix * C + cb8) = o1v[j];
-      if constexpr (!BWD) {
-        if (p.b1 && fq == 0) p.b1[pix * (C / 32) + wn] = b1w[j];
+    }
+  }
+  if constexpr (!BWD) {
+    if (p.b1) {   // h1 > 0 words: lane fq stores fragment fq's (then fragment 4 + fq's) word of its pixel column
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int j = r * 4 + fq;
+        const unsigned w = r == 0 ? sel4(b1w[0], b1w[1], b1w[2], b1w[3]) : sel4(b1w[4], b1w[5], 0u, 0u);
+        const int R = wm * 96 + j * 16 + fr;
+        const int hy = R / HWD, hx = R - hy * HWD;
+        const bool st = j < 6 && ((st1 >> j) & 1u);
+        const int64_t pix = img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx);
+        *(st ? p.b1 + pix * (C / 32) + wn : (unsigned*)g_blk_sink) = w;
       }
     }
   }
@@ -351,7 +379,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   auto o3p = [&](int j) { return pixj[j] >= 0 ? p.o3 + (int64_t)pixj[j] * C4 + chw : (bf16_t*)g_blk_sink; };
   // MB: this lane's pair of words (64 channels: wn) of the x > 0 plane, + nc * (C / 16); forward: lane fq == 0 stores it
   auto b3r = [&](int j) { return (pixj[j] >= 0 && MB) ? p.b3 + (int64_t)pixj[j] * (C4 / 32) + wn * 2 : (const unsigned*)g_blk_zero; };
-  auto b3w = [&](int j) { return (pixj[j] >= 0 && !BWD && p.b3 && fq == 0) ? p.b3 + (int64_t)pixj[j] * (C4 / 32) + wn * 2 : (unsigned*)g_blk_sink; };
   bf16x8_t ad0[4][2], ad1[4][2], mk3[MB ? 1 : 4][2];
   u32x2_t mw3[MB ? 2 : 1][4];    // MB: both passes' word pairs
   auto load_ad = [&](int nc, bf16x8_t (&dst)[4][2]) {
@@ -547,23 +574,35 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
           const bool ok = (y < H) && (x < W);
           const int64_t pix = img_pix0 + (int64_t)y * W + x;
           *(bf16x8_t*)(ok ? p.o2 + pix * C + cb8 : (bf16_t*)g_blk_sink) = o2v[j];
-          if constexpr (!BWD) {
-            if (p.b2) *((ok && fq == 0) ? p.b2 + pix * (C / 32) + wn : (unsigned*)g_blk_sink) = b2w[j];
+        }
+        if constexpr (!BWD) {
+          if (p.b2) {   // h2 > 0 words: lane fq stores tile row wm * 4 + fq's word of its pixel column
+            const int y = y0 + wm * 4 + fq, x = x0 + pi;
+            *((y < H && x < W) ? p.b2 + (img_pix0 + (int64_t)y * W + x) * (C / 32) + wn : (unsigned*)g_blk_sink) =
+                sel4(b2w[0], b2w[1], b2w[2], b2w[3]);
           }
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h) *(bf16x8_t*)(o3p(j) + nc * 128 + h * 8) = ov[j][h];
-        if constexpr (!BWD) {
-          if (p.b3) {   // x > 0 of this lane's 16 channels -> the pixel's 64-channel word pair, stored by lane fq == 0
-            const bf16x8_t (&ad)[4][2] = nc == 0 ? ad0 : ad1;
+      if constexpr (!BWD) {
+        if (p.b3) {   // x > 0: the pixel's 64-channel word pair from the four lanes' 16 bits each; lane fq stores row fq's
+          const bf16x8_t (&ad)[4][2] = nc == 0 ? ad0 : ad1;
+          unsigned lo[4], hi[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
             unsigned v16 = (pos_bits8<F16>(ad[j][0]) | (pos_bits8<F16>(ad[j][1]) << 8)) << (16 * (fq & 1));
             v16 |= __shfl_xor(v16, 16);
             const unsigned other = __shfl_xor(v16, 32);
-            *(u32x2_t*)(b3w(j) + nc * (C / 16)) = (u32x2_t){v16, other};
+            lo[j] = (fq & 2) ? other : v16;
+            hi[j] = (fq & 2) ? v16 : other;
           }
+          const int y = y0 + wm * 4 + fq, x = x0 + fr;
+          unsigned* dst = (y < H && x < W) ? p.b3 + (img_pix0 + (int64_t)y * W + x) * (C4 / 32) + wn * 2 + nc * (C / 16)
+                                           : (unsigned*)g_blk_sink;
+          *(u32x2_t*)dst = (u32x2_t){sel4(lo[0], lo[1], lo[2], lo[3]), sel4(hi[0], hi[1], hi[2], hi[3])};
         }
       }
     }
@@ -690,6 +729,9 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
   const int pi = fr < 4 ? 2 * fr : (fr >= 12 ? 2 * (fr - 8) : 2 * (fr - 4) + 1);
   const int cb8 = wn * 32 + fq * 8;
 
+  // pick element fq of a 4-entry register array (every lane holds all entries after the gathers): lets the four lanes
+  // of a pixel column store four different fragments' words with ONE instruction instead of one lane storing four times
+  auto sel4 = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3) { return fq == 0 ? a0 : (fq == 1 ? a1 : (fq == 2 ? a2 : a3)); };
   auto load_affine = [&](const float* scp, const float* shp, int ch, f32x4_t& sc, f32x4_t& sh) {
     sc = (!BWD && scp) ? *(const f32x4_t*)(scp + ch) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
     sh = (!BWD && shp) ? *(const f32x4_t*)(shp + ch) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -809,8 +851,19 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
       const int hy = R / HWD, hx = R - hy * HWD;
       const int64_t pix = img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx);
       *(bf16x8_t*)(p.o1 + pix * C + cb8) = o1v[j];
-      if constexpr (!BWD) {
-        if (p.b1 && fq == 0) p.b1[pix * (C / 32) + wn] = b1w[j];
+    }
+  }
+  if constexpr (!BWD) {
+    if (p.b1) {   // h1 > 0 words: lane fq stores fragment fq's (then fragment 4 + fq's) word of its pixel column
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int j = r * 4 + fq;
+        const unsigned w = r == 0 ? sel4(b1w[0], b1w[1], b1w[2], b1w[3]) : sel4(b1w[4], b1w[5], 0u, 0u);
+        const int R = wm * 96 + j * 16 + fr;
+        const int hy = R / HWD, hx = R - hy * HWD;
+        const bool st = j < 6 && ((st1 >> j) & 1u);
+        const int64_t pix = img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx);
+        *(st ? p.b1 + pix * (C / 32) + wn : (unsigned*)g_blk_sink) = w;
       }
     }
   }
@@ -840,8 +893,6 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
   auto o3p = [&](int j) { return pixj[j] >= 0 ? p.o3 + (int64_t)pixj[j] * C4 + chw : (bf16_t*)g_blk_sink; };
   auto o2p = [&](int j) { return pixj[j] >= 0 ? p.o2 + (int64_t)pixj[j] * C + cb8 : (bf16_t*)g_blk_sink; };
   auto b3r = [&](int j) { return (pixj[j] >= 0 && MB) ? p.b3 + (int64_t)pixj[j] * (C4 / 32) + wn * 2 : (const unsigned*)g_blk_zero; };
-  auto b3w = [&](int j) { return (pixj[j] >= 0 && !BWD && p.b3 && fq == 0) ? p.b3 + (int64_t)pixj[j] * (C4 / 32) + wn * 2 : (unsigned*)g_blk_sink; };
-  auto b2p = [&](int j) { return (pixj[j] >= 0 && !BWD && p.b2 && fq == 0) ? p.b2 + (int64_t)pixj[j] * (C / 32) + wn : (unsigned*)g_blk_sink; };
   // Phase 3's per-pixel operands (addend, ReLU-mask source).  Loads return in issue order, so a load issued behind a
   // batch of LDS-DMA units is not back before those have landed: the first pass's operands are requested in the middle
   // of phase 2 (8 or 16 unconditional loads, accounted for in the counted waits of the six iterations in which they
@@ -915,6 +966,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
   f32x4_t sc3v[4], sh3v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, chw + 4 * i, sc3v[i], sh3v[i]);
+  unsigned b2w[4];
   {
     f32x4_t sc2v[2], sh2v[2];
 #pragma unroll
@@ -951,7 +1003,14 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
       *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + pr * RB + (((wn * 4 + fq) ^ f256(pr)) * 16)) = o;
       *(bf16x8_t*)o2p(j) = o;           // h2 / g1 to HBM (sink line for pixels outside the image)
       if constexpr (!BWD) {
-        if (p.b2) *b2p(j) = gather_word4(pos_bits8<F16>(o), fq);
+        if (p.b2) b2w[j] = gather_word4(pos_bits8<F16>(o), fq);
+      }
+    }
+    if constexpr (!BWD) {
+      if (p.b2) {   // h2 > 0 words: lane fq stores tile row wm * 4 + fq's word of its pixel column
+        const int y = y0 + wm * 4 + fq, x = x0 + pi;
+        *((y < H && x < W) ? p.b2 + (img_pix0 + (int64_t)y * W + x) * (C / 32) + wn : (unsigned*)g_blk_sink) =
+            sel4(b2w[0], b2w[1], b2w[2], b2w[3]);
       }
     }
   }
@@ -1040,17 +1099,25 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
       for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, 256 + chw + 4 * i, sc3v[i], sh3v[i]);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int h = 0; h < 2; ++h) *(bf16x8_t*)(o3p(j) + nc * 256 + h * 8) = ov[j][h];
-      if constexpr (!BWD) {
-        if (p.b3) {   // x > 0 of this lane's 16 channels -> the pixel's 64-channel word pair, stored by lane fq == 0
-          const bf16x8_t (&ad)[4][2] = nc == 0 ? ad0 : ad1;
+    if constexpr (!BWD) {
+      if (p.b3) {   // x > 0: the pixel's 64-channel word pair from the four lanes' 16 bits each; lane fq stores row fq's
+        const bf16x8_t (&ad)[4][2] = nc == 0 ? ad0 : ad1;
+        unsigned lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
           unsigned v16 = (pos_bits8<F16>(ad[j][0]) | (pos_bits8<F16>(ad[j][1]) << 8)) << (16 * (fq & 1));
           v16 |= __shfl_xor(v16, 16);
           const unsigned other = __shfl_xor(v16, 32);
-          *(u32x2_t*)(b3w(j) + nc * (C / 16)) = (u32x2_t){v16, other};
+          lo[j] = (fq & 2) ? other : v16;
+          hi[j] = (fq & 2) ? v16 : other;
         }
+        const int y = y0 + wm * 4 + fq, x = x0 + pi;
+        unsigned* dst = (y < H && x < W) ? p.b3 + (img_pix0 + (int64_t)y * W + x) * (C4 / 32) + wn * 2 + nc * (C / 16)
+                                         : (unsigned*)g_blk_sink;
+        *(u32x2_t*)dst = (u32x2_t){sel4(lo[0], lo[1], lo[2], lo[3]), sel4(hi[0], hi[1], hi[2], hi[3])};
       }
     }
     // b7: units 22..25 landed.  Behind unit 25 this wave has issued 8 + 8 addend and mask loads (backward without bit

@@ -833,19 +833,36 @@ def _block_fusable(b, C4):
     return ops.bottleneck_supported(1, 1, C)
 
 
+# set by SeqNetFunction.forward for the duration of the call: will a backward pass follow (does any input / parameter of
+# the node need a gradient)?  Inside autograd.Function.forward grad mode is always off, so it cannot be asked there.
+_WANT_BWD = [False]
+
+
+def _block_bits_on():
+    """ReLU bit planes for the one-launch blocks (default on): the forward launch also writes h1 > 0, h2 > 0 and x > 0
+    as 1-bit planes and the backward launch reads those instead of the 16-bit tensors (1/16 of the mask bytes: 37 % of
+    that launch's HBM traffic).  TDN_BLOCK_BITS=0: 16-bit mask sources."""
+    return os.environ.get('TDN_BLOCK_BITS', '1') != '0'
+
+
 def _block_fwd(x, b, bufs=None):
-    """One residual block.  ``bufs`` = caller-provided (h1, h2, out, res) outputs — one image's slices of batch
+    """One residual block.  ``bufs`` = caller-provided (h1, h2, out, res[, bits]) outputs — one image's slices of batch
     tensors when the images of a batch run as separate chains (ImageSplit); everything then stays on the routed
     stream (no branch stream for the downsample conv)."""
     res, br = x, None
-    o1 = o2 = o3 = ores = None
+    o1 = o2 = o3 = ores = bits = None
     if bufs is not None:
-        o1, o2, o3, ores = bufs
+        o1, o2, o3, ores = bufs[:4]
+        bits = bufs[4] if len(bufs) > 4 else None
     if _block_fusable(b, x.shape[3]):
         u1, u2, u3 = b.u1, b.u2, b.u3
+        if bufs is None and _block_bits_on() and _WANT_BWD[0]:
+            bits = ops.bottleneck_bit_planes(x.shape[0], x.shape[1], x.shape[2], u1.Cout, x.device)
         h1, h2, out = ops.bottleneck_fwd(x, u1.w_fwd, u2.w_fwd, u3.w_fwd,
                                          (u1.scale, u1.shift, u2.scale, u2.shift, u3.scale, u3.shift),
-                                         outs=(o1, o2, o3) if bufs is not None else None)
+                                         outs=(o1, o2, o3) if bufs is not None else None, bits=bits)
+        if bufs is None and bits is not None:
+            h1._tdn_bits = bits       # travels with the saved activation to the backward launch
         return out, (x, h1, h2, out)
     if b.ud is not None:
         if bufs is not None:
@@ -915,7 +932,11 @@ def _blocks_fwd_split(blocks, cur):
             h2 = None
             out = new(h1.shape[1], h1.shape[2], b.u2.Cout)
         res = new(out.shape[1], out.shape[2], out.shape[3]) if b.ud is not None else None
-        bufs.append((h1, h2, out, res))
+        bits = None
+        if _block_bits_on() and _WANT_BWD[0] and _block_fusable(b, x.shape[3]):
+            bits = ops.bottleneck_bit_planes(N, H, W, b.u1.Cout, dev)
+            h1._tdn_bits = bits
+        bufs.append((h1, h2, out, res, bits))
         x = out
     ev = streams.record(torch.cuda.current_stream(dev))
     for i in range(ways):
@@ -931,7 +952,7 @@ def _blocks_fwd_split(blocks, cur):
     # GraphedStep capture streams.wait now refuses it with a RuntimeError (the step then runs eager) — to reproduce the
     # crash itself, capture with a plain torch.cuda.graph (not policed).
     chain_sync = int(os.environ.get('TDN_CHAIN_SYNC', '0'))
-    for bi_, (b, (h1, h2, out, res)) in enumerate(zip(blocks, bufs)):
+    for bi_, (b, (h1, h2, out, res, bits)) in enumerate(zip(blocks, bufs)):
         if chain_sync > 0 and bi_ > 0 and bi_ % chain_sync == 0:
             mode = os.environ.get('TDN_CHAIN_SYNC_MODE', 'cross')
             if mode == 'cross':        # every chain waits for every other chain's event of this point
@@ -956,26 +977,33 @@ def _blocks_fwd_split(blocks, cur):
             prev = _lib.set_stream_override(pool[i].cuda_stream)
             try:
                 xs[i], _ = _block_fwd(xs[i], b, (h1[a:e_], h2[a:e_] if h2 is not None else None, out[a:e_],
-                                                 res[a:e_] if res is not None else None))
+                                                 res[a:e_] if res is not None else None,
+                                                 tuple(t[a:e_] for t in bits) if bits is not None else None))
             finally:
                 _lib.set_stream_override(prev)
     main = torch.cuda.current_stream(dev)
     for i in range(ways):
         streams.wait_stream(main, pool[i])
     saved, x = [], cur
-    for (h1, h2, out, res) in bufs:
+    for (h1, h2, out, res, bits) in bufs:
         saved.append((x, h1, h2, out))
         x = out
     return x, saved
 
 
-def _block_dgrad_fused(b, saved, g, mask_src, outs=None):
+def _block_dgrad_fused(b, saved, g, mask_src, outs=None, bits=None):
     """The three input gradients of a fusable block in one launch (g2, g1, dx); with DEBUG_BWD set the launch is
     recorded as the three dgrad launches it replaces — their operands and results all exist in HBM — so the in-situ
     parity checks (tests/parity_util.py) recompute every conv of the fused launch like any other."""
     x, h1, h2, out = saved
     u1, u2, u3 = b.u1, b.u2, b.u3
-    g2, g1, dx = ops.bottleneck_dgrad(g, u3.w_dgrad, u2.w_dgrad, u1.w_dgrad, (h2, h1, mask_src), outs=outs)
+    if bits is None:
+        bits = getattr(h1, '_tdn_bits', None)
+    if bits is not None and mask_src is not None and mask_src.data_ptr() != x.data_ptr():
+        bits = None                    # the third plane is x > 0: only valid when the block's input is the mask source
+    if bits is not None and mask_src is None:
+        bits = None                    # no mask on dx at all (first block of a net without a stem): 16-bit path
+    g2, g1, dx = ops.bottleneck_dgrad(g, u3.w_dgrad, u2.w_dgrad, u1.w_dgrad, (h2, h1, mask_src), outs=outs, bits=bits)
     if DEBUG_BWD is not None:
         DEBUG_BWD.append(('dgrad', u3, g, _hw(h2), None, ADD_NONE, h2, g2))
         DEBUG_BWD.append(('dgrad', u2, g2, _hw(h1), None, ADD_NONE, h1, g1))
@@ -1040,6 +1068,7 @@ def _block_bwd_chains(b, saved, g, extra, mask_src, wq, pool, cuts):
     dx = new_like(x)
     t = new_like(x) if b.ud is not None else g
     fused = extra is None and _block_fusable(b, x.shape[3])
+    bits_all = getattr(h1, '_tdn_bits', None) if fused else None
     for i, st in enumerate(pool[:len(cuts) - 1]):
         a, e = cuts[i], cuts[i + 1]
         prev = _lib.set_stream_override(st.cuda_stream)
@@ -1048,7 +1077,8 @@ def _block_bwd_chains(b, saved, g, extra, mask_src, wq, pool, cuts):
             if fused:
                 _block_dgrad_fused(b, (x[a:e], h1[a:e], h2[a:e], None), gi,
                                    mask_src[a:e] if mask_src is not None else None,
-                                   outs=(g2[a:e], g1[a:e], dx[a:e]))
+                                   outs=(g2[a:e], g1[a:e], dx[a:e]),
+                                   bits=tuple(t[a:e] for t in bits_all) if bits_all is not None else None)
                 continue
             if b.ud is not None:
                 unit_dgrad(b.ud, gi, _hw(x), extra[a:e] if extra is not None else None, ADD_SAME, out=t[a:e])
@@ -1105,8 +1135,13 @@ class SeqNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, *params):
         ctx.gn_saved = {}
-        with gn_scope(ctx.gn_saved):
-            return SeqNetFunction._forward(ctx, net, x, *params)
+        prev = _WANT_BWD[0]
+        _WANT_BWD[0] = any(ctx.needs_input_grad)
+        try:
+            with gn_scope(ctx.gn_saved):
+                return SeqNetFunction._forward(ctx, net, x, *params)
+        finally:
+            _WANT_BWD[0] = prev
 
     @staticmethod
     def _forward(ctx, net, x, *params):
