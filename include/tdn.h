@@ -232,6 +232,24 @@ int tdn_bottleneck_supported(int H, int W, int C, int stride, int dilation);
 int tdn_bottleneck_fwd(const tdn_bottleneck_args* a, int dtype, void* stream);
 int tdn_bottleneck_dgrad(const tdn_bottleneck_args* a, int dtype, void* stream);
 
+/* The stage's FIRST Bottleneck where it keeps the resolution (layer1.0: models/backbone/resnet.py:130-136 builds a
+ * 1x1 conv + BN `downsample` because inplanes != planes * 4; :113-114 adds it instead of x): the block input has Cin
+ * channels and the residual branch is downsample(x).  Built for Cin == C == 64, stride 1.
+ *   forward:  b.in [N][H][W][Cin]; b.w1 [C][1][1][Cin]; b.out3 [N][H][W][4C] = relu(bn3(conv3(out2)) + addend) with
+ *             addend [N][H][W][4C] = the downsample branch (a tdn_conv2d_fwd launch of the caller's);
+ *             bits1 / bits2 optional, bits3 must be NULL
+ *   dgrad:    b.in = g [N][H][W][4C]; b.w3 = conv1 w_dgrad [Cin][1][1][C]; b.out3 = dx [N][H][W][Cin] =
+ *             conv1^T(out2) + addend with addend [N][H][W][Cin] = the downsample conv's input gradient; the block input
+ *             comes from the max pool: no mask3 / bits3; bits1 and bits2 (both or none) replace mask2 / mask1
+ * Bit-identical to the three tdn_conv2d_fwd / tdn_conv2d_dgrad launches it replaces. */
+typedef struct tdn_bottleneck_head_args {
+  tdn_bottleneck_args b;
+  const void* addend;
+} tdn_bottleneck_head_args;
+int tdn_bottleneck_head_supported(int H, int W, int Cin, int C, int stride, int dilation);
+int tdn_bottleneck_head_fwd(const tdn_bottleneck_head_args* a, int dtype, void* stream);
+int tdn_bottleneck_head_dgrad(const tdn_bottleneck_head_args* a, int dtype, void* stream);
+
 /* ---- grouped convolution (ResNeXt) -----------------------------------
  * conv3x3_group(..., groups=cardinality) of models/backbone/resnext.py:26-28,82-83: C channels in and out,
  * `groups` groups.  Computed in block-diagonal form: every 64-channel block of the output multiplies only the same

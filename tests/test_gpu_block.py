@@ -223,3 +223,83 @@ def test_block_relu_bit_planes(ops, generic_tiles, N, H, W, dtype, C):
     torch.cuda.synchronize()
     for name, a, b in (("g2", a2, b2), ("g1", a1, b1), ("dx", ax, bx)):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16)), name
+
+
+# ---------------------------------------------------------------------------------------------------
+# head block: the stage's first Bottleneck with a 1x1 downsample branch (layer1.0; resnet.py:130-136, :113-114)
+# ---------------------------------------------------------------------------------------------------
+def _head_case(N, H, W, dtype, seed):
+    C, C4 = 64, 256
+    x = torch.relu(det_tensor((N, H, W, C), seed + 1)).to(dtype)          # the max pool's output: >= 0
+    w1 = (det_tensor((C, 1, 1, C), seed + 2) * (2.0 / C) ** 0.5).to(dtype)
+    w2 = (det_tensor((C, 3, 3, C), seed + 3) * (2.0 / (9 * C)) ** 0.5).to(dtype)
+    w3 = (det_tensor((C4, 1, 1, C), seed + 4) * (2.0 / C) ** 0.5).to(dtype)
+    wd = (det_tensor((C4, 1, 1, C), seed + 5) * (2.0 / C) ** 0.5).to(dtype)
+    aff = []
+    for i, n in enumerate((C, C, C, C, C4, C4, C4, C4)):
+        t = det_tensor((n,), seed + 10 + i).float()
+        aff.append(t * 0.25 + 1.0 if i % 2 == 0 else t * 0.1)
+    return x, w1, w2, w3, wd, aff
+
+
+HEAD_SHAPES = [(1, 8, 16), (2, 24, 48), (1, 13, 21), (3, 5, 7), (1, 17, 40), (1, 200, 336)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W", HEAD_SHAPES)
+@pytest.mark.parametrize("with_bits", [False, True])
+def test_head_block_forward_and_dgrad(ops, generic_tiles, N, H, W, dtype, with_bits):
+    """Bit for bit against the per-conv launches of layer1.0: downsample conv, conv1, conv2, conv3 + residual, and their
+    input gradients (dx = conv1^T(g1) + downsample^T(g), unmasked)."""
+    C, C4 = 64, 256
+    if not ops.bottleneck_head_supported(H, W, C, C):
+        pytest.skip("no head kernel in this build")
+    x, w1, w2, w3, wd, aff = _head_case(N, H, W, dtype, 100 * H + W + 3)
+    dev = torch.device("cuda")
+    xg, w1g, w2g, w3g, wdg = (t.contiguous().to(dev) for t in (x, w1, w2, w3, wd))
+    affg = [a.to(dev) for a in aff]
+    bits = None
+    if with_bits:
+        bits = ops.bottleneck_bit_planes(N, H, W, C, dev)[:2]
+        for b in bits:
+            b.fill_(0x5A5A5A5A)
+    res = ops.conv2d_fwd(xg, wdg, 1, 1, 0, affg[6], affg[7], relu=False)
+    h1, h2, out = ops.bottleneck_head_fwd(xg, w1g, w2g, w3g, affg[:6], res, bits=bits)
+    r1 = ops.conv2d_fwd(xg, w1g, 1, 1, 0, affg[0], affg[1], relu=True)
+    r2 = ops.conv2d_fwd(r1, w2g, 3, 1, 1, affg[2], affg[3], relu=True)
+    r3 = ops.conv2d_fwd(r2, w3g, 1, 1, 0, affg[4], affg[5], res, ops.ADD_SAME, True)
+    torch.cuda.synchronize()
+    for name, a, b in (("h1", h1, r1), ("h2", h2, r2), ("out", out, r3)):
+        ne = a.view(torch.int16) != b.view(torch.int16)
+        assert not bool(ne.any()), "%s: %d of %d elements differ, first %s" % (name, int(ne.sum()), a.numel(), ne.nonzero()[:4].tolist())
+    if with_bits:
+        for name, b, ref in (("h1", bits[0], h1), ("h2", bits[1], h2)):
+            assert torch.equal(_unpack_bits(b, C), (ref.float().cpu() > 0)), name
+    # fp32 reference of the forward pass
+    xc = x.float().permute(0, 3, 1, 2)
+
+    def bn(z, s, b):
+        return z * s.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    f1 = torch.relu(bn(F.conv2d(xc, _oihw(w1)), aff[0], aff[1])).to(dtype).float()
+    f2 = torch.relu(bn(F.conv2d(f1, _oihw(w2), padding=1), aff[2], aff[3])).to(dtype).float()
+    fr = bn(F.conv2d(xc, _oihw(wd)), aff[6], aff[7]).to(dtype).float()
+    fo = torch.relu(bn(F.conv2d(f2, _oihw(w3)), aff[4], aff[5]) + fr).permute(0, 2, 3, 1)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert max_rel(out.float().cpu(), fo) <= TOL + 2 * ulp
+    # backward
+    w1d, w2d, w3d, wdd = (w.permute(3, 1, 2, 0).contiguous() for w in (w1g, w2g, w3g, wdg))
+    g = torch.where(out > 0, (det_tensor((N, H, W, C4), 555) * 0.1).to(dtype).to(dev), torch.zeros((), device=dev, dtype=dtype))
+    g = g.contiguous()
+    t = ops.conv2d_dgrad(g, wdd, (H, W), 1, 1, 0)
+    if with_bits:
+        g2, g1, dx = ops.bottleneck_head_dgrad(g, w3d, w2d, w1d, None, t, bits=bits)
+    else:
+        g2, g1, dx = ops.bottleneck_head_dgrad(g, w3d, w2d, w1d, (h2, h1), t)
+    q2 = ops.conv2d_dgrad(g, w3d, (H, W), 1, 1, 0, mask_src=h2)
+    q1 = ops.conv2d_dgrad(q2, w2d, (H, W), 3, 1, 1, mask_src=h1)
+    qx = ops.conv2d_dgrad(q1, w1d, (H, W), 1, 1, 0, t, ops.ADD_SAME, None)
+    torch.cuda.synchronize()
+    for name, a, b in (("g2", g2, q2), ("g1", g1, q1), ("dx", dx, qx)):
+        ne = a.view(torch.int16) != b.view(torch.int16)
+        assert not bool(ne.any()), "%s: %d of %d elements differ, first %s" % (name, int(ne.sum()), a.numel(), ne.nonzero()[:4].tolist())
+    assert dx.shape == (N, H, W, C)

@@ -100,6 +100,14 @@ class BottleneckArgs(ctypes.Structure):
 
 _BA = ctypes.POINTER(BottleneckArgs)
 
+
+class BottleneckHeadArgs(ctypes.Structure):
+    """Mirror of ``tdn_bottleneck_head_args`` (include/tdn.h)."""
+    _fields_ = [("b", BottleneckArgs), ("addend", c_void_p)]
+
+
+_BHA = ctypes.POINTER(BottleneckHeadArgs)
+
 # name -> (restype, argtypes); must list every symbol of include/tdn.h (tests/test_abi.py checks this)
 SIGNATURES = {
     "tdn_last_error": (ctypes.c_char_p, []),
@@ -153,6 +161,9 @@ SIGNATURES = {
     "tdn_bottleneck_supported": (c_int, [c_int] * 5),
     "tdn_bottleneck_fwd": (c_int, [_BA, c_int, c_void_p]),
     "tdn_bottleneck_dgrad": (c_int, [_BA, c_int, c_void_p]),
+    "tdn_bottleneck_head_supported": (c_int, [c_int] * 6),
+    "tdn_bottleneck_head_fwd": (c_int, [_BHA, c_int, c_void_p]),
+    "tdn_bottleneck_head_dgrad": (c_int, [_BHA, c_int, c_void_p]),
     "tdn_gconv2d_fwd": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
     "tdn_gconv2d_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 8 + [_EP, c_int, c_void_p]),
     "tdn_gconv2d_wgrad_workspace": (c_i64, [c_int] * 8),

@@ -55,6 +55,10 @@ struct BlockParams {
   unsigned* b1;        // [N][H][W][C / 32]    h1 > 0   (backward: mask of its phase 2 output)
   unsigned* b2;        // [N][H][W][C / 32]    h2 > 0   (backward: mask of its phase 1 output, read on the halo too)
   unsigned* b3;        // [N][H][W][4C / 32]   x > 0    (backward: mask of its phase 3 output)
+  // head variant (first block of layer1: 1x1 downsample on the residual branch, C input channels):
+  const bf16_t* ad;    // forward: [N][H][W][4C] downsample branch (when wd is NULL); backward: [N][H][W][C] its input gradient
+  const bf16_t* wd;    // forward: downsample w_fwd [4C][C]: the branch is computed in phase 3 (ad unused)
+  const float* scd; const float* shd;
   int N, H, W;
   int tiles_x, tiles_y, ntiles, nwg_pad;
   unsigned long long* trace;   // libtdn_trace.so only: 16 x 8-byte stamps per workgroup (scripts/block_trace.py)
@@ -117,10 +121,17 @@ __device__ __forceinline__ unsigned gather_word4(unsigned byte, int fq) {
 // timing-dependent mismatch at 525 co-resident workgroups, never at small grids.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool BWD, bool F16, bool MB = false>
+// HEAD (the stage's first block, resnet.py:130-136 with stride 1: layer1.0): the block input has C channels and the
+// residual branch is a 1x1 conv + BN of it.  Forward: phase 1 runs over K = C (two K-steps), the addend of phase 3 is
+// the downsample branch — read from p.ad (computed by a conv launch of its own), or computed here when p.wd is given.
+// Backward: phases 1 / 2 as usual (g has 4C channels); phase 3 produces C channels, dx = conv1^T(g1) + p.ad where p.ad
+// is the downsample conv's input gradient; no mask (the producer of x is the max pool).
+template <bool BWD, bool F16, bool MB = false, bool HEAD = false>
 __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int C = 64, C4 = 256, TH = 8, TW = 16, HWD = TW + 2, PH = (TH + 2) * HWD /* 180 */, PHP = 192;
+  constexpr int CA = (HEAD && !BWD) ? C : C4;   // channels of p.a = K of phase 1
+  constexpr int KS1 = CA / 32;
   constexpr int ROWB = 128;                    // H1 / H2 / conv2 / conv3 weight rows: 64 channels
   // ---- LDS map (80 KB; two workgroups per CU) ----
   // phase 1: ring of four 32-channel K-steps, S(s) = s * 16384: X[192 rows][64 B] (12 KB) + W1[64 rows][64 B] (4 KB)
@@ -184,13 +195,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
     const int swz = (4 - ((R >> 2) & 3)) & 3;
-    xsrc[it] = (const char*)p.a + ((img_pix0 + (int64_t)y * W + x) * C4 + ((lchunk4 ^ swz) * 8)) * 2;
+    xsrc[it] = (const char*)p.a + ((img_pix0 + (int64_t)y * W + x) * CA + ((lchunk4 ^ swz) * 8)) * 2;
     xok |= ok ? (1u << it) : 0u;
   }
   const char* w1src;
   {
     const int n = wave * 16 + lrow16;
-    w1src = (const char*)p.w1 + ((int64_t)n * C4) * 2 + ((lchunk4 ^ ((4 - ((n >> 3) & 3)) & 3)) * 16);
+    w1src = (const char*)p.w1 + ((int64_t)n * CA) * 2 + ((lchunk4 ^ ((4 - ((n >> 3) & 3)) & 3)) * 16);
   }
   auto load_step = [&](int kc) {   // K-step kc (32 channels) into ring slot kc & 3
     char* sX = smem + (kc & 3) * SLOT;
@@ -243,23 +254,47 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) acc1[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // head, forward: the downsample branch (both passes' addends) is requested first of all — it returns with the first
+  // K-step; anywhere later it would sit behind LDS-DMA batches whose counted waits it must not disturb
+  bf16x8_t ad0[4][2], ad1[4][2];
+  if constexpr (HEAD && !BWD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + wm * 4 + j, x = x0 + fr;
+      const bf16_t* src = ((y < H) && (x < W)) ? p.ad + (img_pix0 + (int64_t)y * W + x) * C4 + wn * 64 + fq * 16
+                                              : (const bf16_t*)g_blk_zero;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ad0[j][h] = *(const bf16x8_t*)(src + h * 8);
+        ad1[j][h] = *(const bf16x8_t*)(src + 128 + h * 8);
+      }
+    }
+  }
   load_step(0);
   load_step(1);
-  load_step(2);
+  if constexpr (KS1 == 8) load_step(2);
+  else load_tap(6);       // [32768, 40960): the third ring slot, which two K-steps never use
 #pragma unroll
-  for (int kc = 0; kc < 8; ++kc) {
+  for (int kc = 0; kc < KS1; ++kc) {
     // every issue slot below is 4 LDS-DMA instructions per wave (a K-step, or two conv2 taps): two of them younger
     // than K-step kc are in flight here
     // lgkmcnt(0): with the loop unrolled the scheduler sinks the MFMAs — and the waits of their fragment reads — below
     // the barrier; a read still queued in the LDS pipe can then be overtaken by the LDS-DMA another wave issues into
     // the same ring slot right behind the barrier (seen: 1 KiB pieces of stale data in ~10 of 525 tiles per launch)
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // K-step kc landed; slot (kc - 1) & 3 is free
+    if constexpr (KS1 == 8) {
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // K-step kc landed; slot (kc - 1) & 3 is free
+    } else {      // two K-steps: behind K-step 0 are K-step 1 (4 instructions per wave) and tap 6 (2)
+      if (kc == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     if (kc == 0) BLK_STAMP(1);
     if (kc == 4) BLK_STAMP(2);
-    if (kc + 3 < 8) load_step(kc + 3);
-    else if (kc == 5) { load_tap(2); load_tap(3); }
-    else if (kc == 6) { load_tap(4); load_tap(5); }
-    else { load_tap(6); }
+    if constexpr (KS1 == 8) {
+      if (kc + 3 < 8) load_step(kc + 3);
+      else if (kc == 5) { load_tap(2); load_tap(3); }
+      else if (kc == 6) { load_tap(4); load_tap(5); }
+      else { load_tap(6); }
+    }
     const char* sX = smem + (kc & 3) * SLOT + (wm * 96 + fr) * 64 + ((fq ^ f_rd32) * 16);
     const char* sW = smem + (kc & 3) * SLOT + XB32 + wrow8 * 64 + ((fq ^ f_rd32) * 16);
     bf16x8_t wf[2], xf[6];
@@ -274,6 +309,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   }
   lds_barrier();   // b0: every wave is done reading the ring
   BLK_STAMP(3);
+  if constexpr (KS1 != 8) {
+    // taps 2..5 go where the two K-steps were.  The epilogue's affine operands are touched first: the compiler waits
+    // vmcnt(0) at the first use of a load it knows about, which must not fall behind these eight instructions
+    asm volatile("" ::"v"(sc1v[0]), "v"(sc1v[1]), "v"(sh1v[0]), "v"(sh1v[1]));
+    load_tap(2); load_tap(3); load_tap(4); load_tap(5);
+  }
 
   bf16x8_t o1v[6];
   unsigned b1w[6];                // forward: the h1 > 0 word of the pixel (32 channels: this wave's wn)
@@ -317,8 +358,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       }
     }
   }
-  // b1: H1 complete (LDS writes of every wave), taps 2..6 landed (taps 0 / 1 long ago)
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // b1: H1 complete (LDS writes of every wave), taps 2..6 landed (taps 0 / 1 long ago); two K-steps: taps 2..5 (eight
+  // instructions per wave) are still travelling and are waited for at b2
+  if constexpr (KS1 == 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   BLK_STAMP(4);
   // h1 / g2 to HBM: behind the barrier, so that nobody waits for the stores
 #pragma unroll
@@ -374,12 +417,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     const int y = y0 + wm * 4 + j, x = x0 + fr;
     pixj[j] = ((y < H) && (x < W)) ? (int)(img_pix0 + (int64_t)y * W + x) : -1;
   }
-  auto adp = [&](int j) { return pixj[j] >= 0 ? p.a + (int64_t)pixj[j] * C4 + chw : (const bf16_t*)g_blk_zero; };
+  auto adp = [&](int j) { return pixj[j] >= 0 ? (HEAD ? p.ad : p.a) + (int64_t)pixj[j] * C4 + chw : (const bf16_t*)g_blk_zero; };
   auto mkp = [&](int j) { return (pixj[j] >= 0 && p.m3 && !MB) ? p.m3 + (int64_t)pixj[j] * C4 + chw : (const bf16_t*)g_blk_zero; };
   auto o3p = [&](int j) { return pixj[j] >= 0 ? p.o3 + (int64_t)pixj[j] * C4 + chw : (bf16_t*)g_blk_sink; };
   // MB: this lane's pair of words (64 channels: wn) of the x > 0 plane, + nc * (C / 16); forward: lane fq == 0 stores it
   auto b3r = [&](int j) { return (pixj[j] >= 0 && MB) ? p.b3 + (int64_t)pixj[j] * (C4 / 32) + wn * 2 : (const unsigned*)g_blk_zero; };
-  bf16x8_t ad0[4][2], ad1[4][2], mk3[MB ? 1 : 4][2];
+  bf16x8_t mk3[MB ? 1 : 4][2];
   u32x2_t mw3[MB ? 2 : 1][4];    // MB: both passes' word pairs
   auto load_ad = [&](int nc, bf16x8_t (&dst)[4][2]) {
 #pragma unroll
@@ -395,14 +438,21 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
         for (int h = 0; h < 2; ++h) mk3[j][h] = *(const bf16x8_t*)(mkp(j) + nc * 128 + h * 8);
     }
   };
-  load_ad(0, ad0);
-  if constexpr (BWD && !MB) load_mask3(0);
-  else load_ad(1, ad1);      // forward, and backward with bit planes (8 B of mask per pixel instead of 32 B per pass)
-  if constexpr (MB) {
+  bf16x8_t adh[(BWD && HEAD) ? 4 : 1];   // head, backward: this lane's 8 channels of the downsample branch's input gradient
+  if constexpr (BWD && HEAD) {
 #pragma unroll
-    for (int nc = 0; nc < 2; ++nc)
+    for (int j = 0; j < 4; ++j)
+      adh[j] = *(const bf16x8_t*)(pixj[j] >= 0 ? p.ad + (int64_t)pixj[j] * C + cb8 : (const bf16_t*)g_blk_zero);
+  } else if constexpr (!HEAD) {
+    load_ad(0, ad0);
+    if constexpr (BWD && !MB) load_mask3(0);
+    else load_ad(1, ad1);      // forward, and backward with bit planes (8 B of mask per pixel instead of 32 B per pass)
+    if constexpr (MB) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mw3[nc][j] = *(const u32x2_t*)(b3r(j) + nc * (C / 16));
+      for (int nc = 0; nc < 2; ++nc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mw3[nc][j] = *(const u32x2_t*)(b3r(j) + nc * (C / 16));
+    }
   }
 
   // ================= phase 2: H2[8x16][C] =================
@@ -433,7 +483,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   };
   tap_compute(0);
   tap_compute(1);
-  lds_barrier();   // b2: [65536, 81920) is free
+  if constexpr (KS1 == 8) lds_barrier();   // b2: [65536, 81920) is free
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and taps 2..5 have landed
   BLK_STAMP(5);
   load_tap(7);
   load_tap(8);
@@ -442,11 +493,20 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // b3: taps 7, 8 landed; [0, 40960) is free
   BLK_STAMP(6);
   // conv3 weights [4C][C] into [0, 32768) while taps 7 and 8 are multiplied
+  if constexpr (BWD && HEAD) {   // [C][C]: one tap's worth, in the taps' layout
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int g8 = it * 4 + wave;
-    const int n = g8 * 8 + lrow8;
-    glds16_async((const char*)p.w3 + (int64_t)n * C * 2 + ((lchunk8 ^ swz_w16(n)) * 16), smem + W3_OFF + g8 * 8 * ROWB);
+    for (int it = 0; it < 2; ++it) {
+      const int g8 = it * 4 + wave;
+      const int n = g8 * 8 + lrow8;
+      glds16_async((const char*)p.w3 + (int64_t)n * C * 2 + ((lchunk8 ^ swz_w8(n)) * 16), smem + W3_OFF + g8 * 8 * ROWB);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int g8 = it * 4 + wave;
+      const int n = g8 * 8 + lrow8;
+      glds16_async((const char*)p.w3 + (int64_t)n * C * 2 + ((lchunk8 ^ swz_w16(n)) * 16), smem + W3_OFF + g8 * 8 * ROWB);
+    }
   }
   f32x4_t sc2v[2], sh2v[2];
 #pragma unroll
@@ -500,7 +560,48 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   BLK_STAMP(8);
   // ================= phase 3: OUT[8x16][4C], two passes of 128 channels =================
   const int wrow16 = (wn * 64 + (fr >> 2) * 16 + (fr & 3)) * ROWB;   // + 4i rows: 16 consecutive channels per lane
-  {
+  if constexpr (BWD && HEAD) {
+    // dx[8x16][C] = W1d[C][C] . G1 + (downsample branch's input gradient): one pass in the shape of a conv2 tap
+    f32x4_t acc3[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc3[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const char* sW = smem + W3_OFF + wrow8 * ROWB;
+    const char* sX = smem + H2_OFF + (wm * 64 + fr) * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t wf[2], xf[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[i] = lds_read_b128(sW + i * 4 * ROWB + (((kk * 4 + fq) ^ f_rd_w) * 16));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = lds_read_b128(sX + j * 16 * ROWB + (((kk * 4 + fq) ^ f_rd) * 16));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc3[i][j] = mfma16<F16>(wf[i], xf[j], acc3[i][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // g1 to HBM
+      const int y = y0 + wm * 4 + j, x = x0 + pi;
+      const bool ok = (y < H) && (x < W);
+      const int64_t pix = img_pix0 + (int64_t)y * W + x;
+      *(bf16x8_t*)(ok ? p.o2 + pix * C + cb8 : (bf16_t*)g_blk_sink) = o2v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // fma(acc, 1, 0) + addend: the arithmetic of conv_gemm_kernel's epilogue without scale / shift
+        o[e] = f32_to_elem<F16>((acc3[0][j][e] * 1.f + 0.f) + elem_to_f32<F16>(adh[j][e]));
+        o[4 + e] = f32_to_elem<F16>((acc3[1][j][e] * 1.f + 0.f) + elem_to_f32<F16>(adh[j][4 + e]));
+      }
+      *(bf16x8_t*)(pixj[j] >= 0 ? p.o3 + (int64_t)pixj[j] * C + cb8 : (bf16_t*)g_blk_sink) = o;
+    }
+    BLK_STAMP(9);
+    BLK_STAMP(10);
+  } else {
 #pragma unroll
     for (int nc = 0; nc < 2; ++nc) {
       __builtin_amdgcn_sched_barrier(0);   // keep the passes apart: hoisting the second one's loads and MFMAs spills
@@ -587,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h) *(bf16x8_t*)(o3p(j) + nc * 128 + h * 8) = ov[j][h];
-      if constexpr (!BWD) {
+      if constexpr (!BWD && !HEAD) {
         if (p.b3) {   // x > 0: the pixel's 64-channel word pair from the four lanes' 16 bits each; lane fq stores row fq's
           const bf16x8_t (&ad)[4][2] = nc == 0 ? ad0 : ad1;
           unsigned lo[4], hi[4];
@@ -1136,22 +1237,22 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-template <bool BWD, bool F16, bool MB = false>
+template <bool BWD, bool F16, bool MB = false, bool HEAD = false>
 static int launch_block64(BlockParams& p, hipStream_t stream) {
   constexpr int lds = 81920;
   static tdn_attr_once attr_once;
   if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute((const void*)bottleneck64_kernel<BWD, F16, MB>,
+    hipError_t e = hipFuncSetAttribute((const void*)bottleneck64_kernel<BWD, F16, MB, HEAD>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
     attr_once.mark();
     if (getenv("TDN_DEBUG_OCC")) {
       int nb = -1;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bottleneck64_kernel<BWD, F16, MB>, 256, lds);
-      fprintf(stderr, "[tdn] bottleneck64<%d,%d>: %d B LDS, %d workgroups/CU\n", (int)BWD, (int)F16, lds, nb);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bottleneck64_kernel<BWD, F16, MB, HEAD>, 256, lds);
+      fprintf(stderr, "[tdn] bottleneck64<%d,%d,%d,%d>: %d B LDS, %d workgroups/CU\n", (int)BWD, (int)F16, (int)MB, (int)HEAD, lds, nb);
     }
   }
-  TDN_LAUNCH((bottleneck64_kernel<BWD, F16, MB>), dim3(p.nwg_pad), dim3(256), lds, stream, p);
+  TDN_LAUNCH((bottleneck64_kernel<BWD, F16, MB, HEAD>), dim3(p.nwg_pad), dim3(256), lds, stream, p);
   TDN_LAUNCH_CHECK();
   return 0;
 }
@@ -1234,4 +1335,42 @@ extern "C" int tdn_bottleneck_dgrad(const tdn_bottleneck_args* a, int dtype, voi
   }
   if (dtype == TDN_F16) return launch_block64<true, true>(p, (hipStream_t)stream);
   return launch_block64<true, false>(p, (hipStream_t)stream);
+}
+
+// ---- head block (layer1.0): C input channels, 1x1 downsample on the residual branch ----
+extern "C" int tdn_bottleneck_head_supported(int H, int W, int Cin, int C, int stride, int dilation) {
+  return (Cin == 64 && C == 64 && stride == 1 && dilation == 1 && H > 0 && W > 0) ? 1 : 0;
+}
+
+extern "C" int tdn_bottleneck_head_fwd(const tdn_bottleneck_head_args* a, int dtype, void* stream) {
+  BlockParams p;
+  TDN_CHECK(a != nullptr, "bottleneck head: NULL argument block");
+  if (block_common(p, &a->b, dtype)) return -1;
+  TDN_CHECK(a->b.C == 64, "bottleneck head: C=%d is not built (64)", a->b.C);
+  TDN_CHECK(a->addend != nullptr, "bottleneck head fwd: the downsample branch (addend) is required");
+  TDN_CHECK(a->b.bits3 == nullptr, "bottleneck head fwd: there is no bits3 plane (the block input is not masked)");
+  p.sc1 = a->b.scale1; p.sh1 = a->b.shift1; p.sc2 = a->b.scale2; p.sh2 = a->b.shift2; p.sc3 = a->b.scale3; p.sh3 = a->b.shift3;
+  p.b1 = (unsigned*)a->b.bits1; p.b2 = (unsigned*)a->b.bits2;
+  p.ad = (const bf16_t*)a->addend;
+  if (dtype == TDN_F16) return launch_block64<false, true, false, true>(p, (hipStream_t)stream);
+  return launch_block64<false, false, false, true>(p, (hipStream_t)stream);
+}
+
+extern "C" int tdn_bottleneck_head_dgrad(const tdn_bottleneck_head_args* a, int dtype, void* stream) {
+  BlockParams p;
+  TDN_CHECK(a != nullptr, "bottleneck head: NULL argument block");
+  if (block_common(p, &a->b, dtype)) return -1;
+  TDN_CHECK(a->b.C == 64, "bottleneck head: C=%d is not built (64)", a->b.C);
+  TDN_CHECK(a->addend != nullptr, "bottleneck head dgrad: the downsample branch's input gradient (addend) is required");
+  TDN_CHECK(a->b.mask3 == nullptr && a->b.bits3 == nullptr, "bottleneck head dgrad: the block input gradient takes no mask");
+  p.m1 = (const bf16_t*)a->b.mask1; p.m2 = (const bf16_t*)a->b.mask2;
+  p.b1 = (unsigned*)a->b.bits1; p.b2 = (unsigned*)a->b.bits2;
+  p.ad = (const bf16_t*)a->addend;
+  if (a->b.bits1 || a->b.bits2) {
+    TDN_CHECK(a->b.bits1 && a->b.bits2, "bottleneck head dgrad: both bit planes or none");
+    if (dtype == TDN_F16) return launch_block64<true, true, true, true>(p, (hipStream_t)stream);
+    return launch_block64<true, false, true, true>(p, (hipStream_t)stream);
+  }
+  if (dtype == TDN_F16) return launch_block64<true, true, false, true>(p, (hipStream_t)stream);
+  return launch_block64<true, false, false, true>(p, (hipStream_t)stream);
 }

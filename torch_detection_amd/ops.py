@@ -271,20 +271,23 @@ def bottleneck_bit_planes(N, H, W, C, device):
     return mk(C), mk(C), mk(4 * C)
 
 
-def _bottleneck_args(name, a, w1, w2, w3, affine, masks, outs, bits=None):
+def _bottleneck_args(name, a, w1, w2, w3, affine, masks, outs, bits=None, head=None):
+    """``head``: None, 'fwd' (a has C channels, out3 4C) or 'bwd' (a has 4C channels, out3 C) — the layer1.0 geometry."""
     _chk_act(a, "in")
-    N, H, W, C4 = a.shape
-    C = C4 // 4
-    if C * 4 != C4:
-        raise ValueError("%s: %d input channels are not 4 x the mid channels" % (name, C4))
-    for w, shp, nm in ((w1, (C, 1, 1, C4), "w1"), (w2, (C, 3, 3, C), "w2"), (w3, (C4, 1, 1, C), "w3")):
+    N, H, W, CA = a.shape
+    C = CA if head == 'fwd' else CA // 4
+    C4 = 4 * C
+    if head != 'fwd' and C * 4 != CA:
+        raise ValueError("%s: %d input channels are not 4 x the mid channels" % (name, CA))
+    C3 = C if head == 'bwd' else C4          # channels of out3
+    for w, shp, nm in ((w1, (C, 1, 1, CA), "w1"), (w2, (C, 3, 3, C), "w2"), (w3, (C3, 1, 1, C), "w3")):
         if w.dtype != a.dtype or tuple(w.shape) != shp or not w.is_contiguous() or not w.is_cuda:
             raise ValueError("%s: %s must be %s %s contiguous, got %s %s" % (name, nm, a.dtype, shp, w.dtype,
                                                                               tuple(w.shape)))
     o1, o2, o3 = outs if outs is not None else (None, None, None)
     o1 = torch.empty(N, H, W, C, dtype=a.dtype, device=a.device) if o1 is None else _out_buffer(o1, (N, H, W, C), a.dtype, name)
     o2 = torch.empty(N, H, W, C, dtype=a.dtype, device=a.device) if o2 is None else _out_buffer(o2, (N, H, W, C), a.dtype, name)
-    o3 = torch.empty(N, H, W, C4, dtype=a.dtype, device=a.device) if o3 is None else _out_buffer(o3, (N, H, W, C4), a.dtype, name)
+    o3 = torch.empty(N, H, W, C3, dtype=a.dtype, device=a.device) if o3 is None else _out_buffer(o3, (N, H, W, C3), a.dtype, name)
     args = _lib.BottleneckArgs()
     args.in_, args.w1, args.w2, args.w3 = a.data_ptr(), w1.data_ptr(), w2.data_ptr(), w3.data_ptr()
     if affine is not None:
@@ -337,6 +340,50 @@ def bottleneck_dgrad(g, w3d, w2d, w1d, masks, outs=None, bits=None):
     args, o = _bottleneck_args("bottleneck_dgrad", g, w3d, w2d, w1d, None, None if bits is not None else masks, outs, bits)
     _lib.check(_lib.load().tdn_bottleneck_dgrad(ctypes.byref(args), dtype_code(g.dtype), _lib.stream_ptr()),
                "tdn_bottleneck_dgrad")
+    return o
+
+
+def bottleneck_head_supported(H, W, Cin, C, stride=1, dilation=1):
+    """Does this build have a one-launch kernel for a stage's first Bottleneck (1x1 downsample branch, Cin inputs)?"""
+    return bool(_lib.load().tdn_bottleneck_head_supported(int(H), int(W), int(Cin), int(C), int(stride), int(dilation)))
+
+
+def _head_args(args, addend, shape, dtype, name):
+    _chk_act(addend, "addend", shape[3], dtype)
+    if tuple(addend.shape) != tuple(shape):
+        raise ValueError("%s: addend has shape %s, expected %s" % (name, tuple(addend.shape), tuple(shape)))
+    h = _lib.BottleneckHeadArgs()
+    h.b = args
+    h.addend = addend.data_ptr()
+    return h
+
+
+def bottleneck_head_fwd(x, w1, w2, w3, affine, res, outs=None, bits=None):
+    """First Bottleneck of layer1 (resnet.py:130-136: 1x1 downsample because inplanes != 4 * planes; stride 1) in one
+    launch: x [N,H,W,C], ``res`` [N,H,W,4C] = the downsample branch (conv + BN, a launch of its own); returns
+    (h1, h2, out) with out = relu(bn3(conv3(h2)) + res).  ``bits`` = optional (b1, b2) planes."""
+    N, H, W, C = x.shape
+    bits3 = (bits[0], bits[1], None) if bits is not None else None
+    args, o = _bottleneck_args("bottleneck_head_fwd", x, w1, w2, w3, affine, None, outs, bits3, head='fwd')
+    h = _head_args(args, res, (N, H, W, 4 * C), x.dtype, "bottleneck_head_fwd")
+    _lib.check(_lib.load().tdn_bottleneck_head_fwd(ctypes.byref(h), dtype_code(x.dtype), _lib.stream_ptr()),
+               "tdn_bottleneck_head_fwd")
+    return o
+
+
+def bottleneck_head_dgrad(g, w3d, w2d, w1d, masks, t, outs=None, bits=None):
+    """Input-gradient chain of that block in one launch: g [N,H,W,4C]; ``t`` [N,H,W,C] = the downsample conv's input
+    gradient; returns (g2, g1, dx) with dx = conv1^T(g1) + t (no mask: x comes from the max pool).  ``masks`` =
+    (h2, h1); ``bits`` = the (b1, b2) planes of the forward call, used instead."""
+    N, H, W, C4 = g.shape
+    if bits is not None and any(b is None for b in bits[:2]):
+        raise ValueError("bottleneck_head_dgrad: both bit planes or none")
+    bits3 = (bits[0], bits[1], None) if bits is not None else None
+    m3 = None if bits is not None else (masks[0], masks[1], None)
+    args, o = _bottleneck_args("bottleneck_head_dgrad", g, w3d, w2d, w1d, None, m3, outs, bits3, head='bwd')
+    h = _head_args(args, t, (N, H, W, C4 // 4), g.dtype, "bottleneck_head_dgrad")
+    _lib.check(_lib.load().tdn_bottleneck_head_dgrad(ctypes.byref(h), dtype_code(g.dtype), _lib.stream_ptr()),
+               "tdn_bottleneck_head_dgrad")
     return o
 
 
