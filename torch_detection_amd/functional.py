@@ -833,6 +833,26 @@ def _block_fusable(b, C4):
     return ops.bottleneck_supported(1, 1, C)
 
 
+def _block_head_fusable(b, Cin):
+    """The stage's first Bottleneck where it keeps the resolution (layer1.0, resnet.py:130-136: a 1x1 conv + BN
+    downsample because inplanes != 4 * planes): conv1 -> conv2 -> conv3 + residual run as one launch whose residual is
+    the downsample branch, computed by a launch of its own (ops.bottleneck_head_fwd / _dgrad).  TDN_BLOCK_HEAD=0 (or
+    TDN_BLOCK_FUSE=0) keeps the per-conv launches."""
+    if b.kind != 'bottleneck' or b.ud is None or b.stride != 1:
+        return False
+    if os.environ.get('TDN_BLOCK_FUSE', '1') == '0' or os.environ.get('TDN_BLOCK_HEAD', '1') == '0':
+        return False
+    u1, u2, u3, ud = b.u1, b.u2, b.u3, b.ud
+    for u in (u1, u2, u3, ud):
+        if u.gn or u.bnt or u.groups != 1 or u.act6 or u.bias_and_norm or u.is_stem or u.stride != 1:
+            return False
+    C = u1.Cout
+    if not (u1.k == 1 and u3.k == 1 and ud.k == 1 and u2.k == 3 and u2.pad == 1 and u1.Cin == Cin and ud.Cin == Cin and
+            u3.Cout == 4 * C and ud.Cout == 4 * C and u2.Cin == C and u2.Cout == C and u3.Cin == C):
+        return False
+    return ops.bottleneck_head_supported(1, 1, Cin, C)
+
+
 # set by SeqNetFunction.forward for the duration of the call: will a backward pass follow (does any input / parameter of
 # the node need a gradient)?  Inside autograd.Function.forward grad mode is always off, so it cannot be asked there.
 _WANT_BWD = [False]
@@ -863,6 +883,17 @@ def _block_fwd(x, b, bufs=None):
                                          outs=(o1, o2, o3) if bufs is not None else None, bits=bits)
         if bufs is None and bits is not None:
             h1._tdn_bits = bits       # travels with the saved activation to the backward launch
+        return out, (x, h1, h2, out)
+    if _block_head_fusable(b, x.shape[3]):
+        u1, u2, u3 = b.u1, b.u2, b.u3
+        res = unit_fwd(b.ud, x, relu=False, out=ores)
+        if bufs is None and _block_bits_on() and _WANT_BWD[0]:
+            bits = ops.bottleneck_bit_planes(x.shape[0], x.shape[1], x.shape[2], u1.Cout, x.device)[:2]
+        h1, h2, out = ops.bottleneck_head_fwd(x, u1.w_fwd, u2.w_fwd, u3.w_fwd,
+                                              (u1.scale, u1.shift, u2.scale, u2.shift, u3.scale, u3.shift), res,
+                                              outs=(o1, o2, o3) if bufs is not None else None, bits=bits)
+        if bufs is None and bits is not None:
+            h1._tdn_bits = bits
         return out, (x, h1, h2, out)
     if b.ud is not None:
         if bufs is not None:
@@ -935,6 +966,9 @@ def _blocks_fwd_split(blocks, cur):
         bits = None
         if _block_bits_on() and _WANT_BWD[0] and _block_fusable(b, x.shape[3]):
             bits = ops.bottleneck_bit_planes(N, H, W, b.u1.Cout, dev)
+            h1._tdn_bits = bits
+        elif _block_bits_on() and _WANT_BWD[0] and _block_head_fusable(b, x.shape[3]):
+            bits = ops.bottleneck_bit_planes(N, H, W, b.u1.Cout, dev)[:2]
             h1._tdn_bits = bits
         bufs.append((h1, h2, out, res, bits))
         x = out
@@ -1011,6 +1045,23 @@ def _block_dgrad_fused(b, saved, g, mask_src, outs=None, bits=None):
     return g2, g1, dx
 
 
+def _block_head_dgrad_fused(b, saved, g, outs=None, bits=None, t_out=None):
+    """Input gradients of a head block (_block_head_fusable): the downsample conv's dgrad as a launch of its own, then
+    g2, g1 and dx = conv1^T(g1) + t in one launch.  Returns (g2, g1, dx, t)."""
+    x, h1, h2, out = saved
+    u1, u2, u3 = b.u1, b.u2, b.u3
+    if bits is None:
+        bits = getattr(h1, '_tdn_bits', None)
+    t = unit_dgrad(b.ud, g, _hw(x), out=t_out)
+    g2, g1, dx = ops.bottleneck_head_dgrad(g, u3.w_dgrad, u2.w_dgrad, u1.w_dgrad, (h2, h1), t, outs=outs,
+                                           bits=bits[:2] if bits is not None else None)
+    if DEBUG_BWD is not None:
+        DEBUG_BWD.append(('dgrad', u3, g, _hw(h2), None, ADD_NONE, h2, g2))
+        DEBUG_BWD.append(('dgrad', u2, g2, _hw(h1), None, ADD_NONE, h1, g1))
+        DEBUG_BWD.append(('dgrad', u1, g1, _hw(x), t, ADD_SAME, None, dx))
+    return g2, g1, dx, t
+
+
 def _block_bwd(b, saved, g, extra, mask_src, need_dx, wq=None):
     """g: gradient w.r.t. the block's pre-ReLU output, already masked by (out > 0).
     extra: external gradient w.r.t. the block INPUT to fold in (e.g. the FPN's gradient of a stage output).
@@ -1024,6 +1075,13 @@ def _block_bwd(b, saved, g, extra, mask_src, need_dx, wq=None):
         grads[b.u3] = unit_wgrad(b.u3, h2, g, queue=wq)
         grads[b.u2] = unit_wgrad(b.u2, h1, g2, queue=wq)
         grads[b.u1] = unit_wgrad(b.u1, x, g1, queue=wq)
+        return dx, grads
+    if need_dx and extra is None and mask_src is None and _block_head_fusable(b, x.shape[3]):
+        g2, g1, dx, _ = _block_head_dgrad_fused(b, saved, g)
+        grads[b.u3] = unit_wgrad(b.u3, h2, g, queue=wq)
+        grads[b.u2] = unit_wgrad(b.u2, h1, g2, queue=wq)
+        grads[b.u1] = unit_wgrad(b.u1, x, g1, queue=wq)
+        grads[b.ud] = unit_wgrad(b.ud, x, g, queue=wq)
         return dx, grads
     if need_dx and b.ud is not None:
         with branch(g.device, b.ud, (g, extra) if extra is not None else (g,)) as br:
@@ -1068,7 +1126,8 @@ def _block_bwd_chains(b, saved, g, extra, mask_src, wq, pool, cuts):
     dx = new_like(x)
     t = new_like(x) if b.ud is not None else g
     fused = extra is None and _block_fusable(b, x.shape[3])
-    bits_all = getattr(h1, '_tdn_bits', None) if fused else None
+    head = extra is None and mask_src is None and _block_head_fusable(b, x.shape[3])
+    bits_all = getattr(h1, '_tdn_bits', None) if (fused or head) else None
     for i, st in enumerate(pool[:len(cuts) - 1]):
         a, e = cuts[i], cuts[i + 1]
         prev = _lib.set_stream_override(st.cuda_stream)
@@ -1079,6 +1138,11 @@ def _block_bwd_chains(b, saved, g, extra, mask_src, wq, pool, cuts):
                                    mask_src[a:e] if mask_src is not None else None,
                                    outs=(g2[a:e], g1[a:e], dx[a:e]),
                                    bits=tuple(t[a:e] for t in bits_all) if bits_all is not None else None)
+                continue
+            if head:
+                _block_head_dgrad_fused(b, (x[a:e], h1[a:e], h2[a:e], None), gi, outs=(g2[a:e], g1[a:e], dx[a:e]),
+                                        bits=tuple(t_[a:e] for t_ in bits_all) if bits_all is not None else None,
+                                        t_out=t[a:e])
                 continue
             if b.ud is not None:
                 unit_dgrad(b.ud, gi, _hw(x), extra[a:e] if extra is not None else None, ADD_SAME, out=t[a:e])
