@@ -236,7 +236,8 @@ int tdn_bottleneck_dgrad(const tdn_bottleneck_args* a, int dtype, void* stream);
  * 1x1 conv + BN `downsample` because inplanes != planes * 4; :113-114 adds it instead of x): the block input has Cin
  * channels and the residual branch is downsample(x).  Built for Cin == C == 64, stride 1.
  *   forward:  b.in [N][H][W][Cin]; b.w1 [C][1][1][Cin]; b.out3 [N][H][W][4C] = relu(bn3(conv3(out2)) + addend) with
- *             addend [N][H][W][4C] = the downsample branch (a tdn_conv2d_fwd launch of the caller's);
+ *             addend [N][H][W][4C] = the downsample branch (a tdn_conv2d_fwd launch of the caller's), or computed in
+ *             the launch from wd / scale_d / shift_d (see below);
  *             bits1 / bits2 optional, bits3 must be NULL
  *   dgrad:    b.in = g [N][H][W][4C]; b.w3 = conv1 w_dgrad [Cin][1][1][C]; b.out3 = dx [N][H][W][Cin] =
  *             conv1^T(out2) + addend with addend [N][H][W][Cin] = the downsample conv's input gradient; the block input
@@ -245,6 +246,11 @@ int tdn_bottleneck_dgrad(const tdn_bottleneck_args* a, int dtype, void* stream);
 typedef struct tdn_bottleneck_head_args {
   tdn_bottleneck_args b;
   const void* addend;
+  /* forward only, INSTEAD of addend: the downsample conv's w_fwd [4C][1][1][Cin] and folded BN [4C] (NULL = 1 / 0) —
+   * the branch is then computed inside the launch (same K order, affine and 16-bit rounding as its own launch would
+   * apply, so the result is still bit-identical) and never travels through HBM */
+  const void* wd;
+  const float* scale_d; const float* shift_d;
 } tdn_bottleneck_head_args;
 int tdn_bottleneck_head_supported(int H, int W, int Cin, int C, int stride, int dilation);
 int tdn_bottleneck_head_fwd(const tdn_bottleneck_head_args* a, int dtype, void* stream);

@@ -272,6 +272,13 @@ def test_head_block_forward_and_dgrad(ops, generic_tiles, N, H, W, dtype, with_b
     for name, a, b in (("h1", h1, r1), ("h2", h2, r2), ("out", out, r3)):
         ne = a.view(torch.int16) != b.view(torch.int16)
         assert not bool(ne.any()), "%s: %d of %d elements differ, first %s" % (name, int(ne.sum()), a.numel(), ne.nonzero()[:4].tolist())
+    # the same block with the downsample branch computed inside the launch
+    k1, k2, kout = ops.bottleneck_head_fwd(xg, w1g, w2g, w3g, affg[:6], None, bits=bits, down=(wdg, affg[6], affg[7]))
+    torch.cuda.synchronize()
+    for name, a, b in (("h1", k1, r1), ("h2", k2, r2), ("out", kout, r3)):
+        ne = a.view(torch.int16) != b.view(torch.int16)
+        assert not bool(ne.any()), "in-launch downsample, %s: %d of %d elements differ, first %s" % (
+            name, int(ne.sum()), a.numel(), ne.nonzero()[:4].tolist())
     if with_bits:
         for name, b, ref in (("h1", bits[0], h1), ("h2", bits[1], h2)):
             assert torch.equal(_unpack_bits(b, C), (ref.float().cpu() > 0)), name

@@ -103,7 +103,8 @@ _BA = ctypes.POINTER(BottleneckArgs)
 
 class BottleneckHeadArgs(ctypes.Structure):
     """Mirror of ``tdn_bottleneck_head_args`` (include/tdn.h)."""
-    _fields_ = [("b", BottleneckArgs), ("addend", c_void_p)]
+    _fields_ = [("b", BottleneckArgs), ("addend", c_void_p), ("wd", c_void_p), ("scale_d", c_void_p),
+                ("shift_d", c_void_p)]
 
 
 _BHA = ctypes.POINTER(BottleneckHeadArgs)

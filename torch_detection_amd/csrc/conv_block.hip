@@ -126,12 +126,20 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // the downsample branch — read from p.ad (computed by a conv launch of its own), or computed here when p.wd is given.
 // Backward: phases 1 / 2 as usual (g has 4C channels); phase 3 produces C channels, dx = conv1^T(g1) + p.ad where p.ad
 // is the downsample conv's input gradient; no mask (the producer of x is the max pool).
-template <bool BWD, bool F16, bool MB = false, bool HEAD = false>
+// HEAD == 2 (forward only): the downsample branch is computed HERE — phase 3 becomes, per pass of 128 output
+// channels, a GEMM of the block input's tile with the downsample weights (result affine-mapped and rounded to 16 bit:
+// the value the separate launch would have stored) followed by the conv3 GEMM whose epilogue adds it.  LDS from b3 on:
+//   [0, 16384)        X2: the tile's 128 pixels x C input channels, rows in H2's layout      (issued at b3)
+//   [16384, 32768)    downsample rows 0..127 (b3); after the first pass's downsample GEMM: conv3 rows 128..255
+//   [32768, 40960)    conv3 rows 0..63 (b3)          [57344, 65536)  conv3 rows 64..127 (b4)
+//   [40960, 57344)    H2                             [65536, 81920)  downsample rows 128..255 (b4)
+template <bool BWD, bool F16, bool MB = false, int HEAD = 0>
 __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int C = 64, C4 = 256, TH = 8, TW = 16, HWD = TW + 2, PH = (TH + 2) * HWD /* 180 */, PHP = 192;
   constexpr int CA = (HEAD && !BWD) ? C : C4;   // channels of p.a = K of phase 1
   constexpr int KS1 = CA / 32;
+  constexpr bool DSK = HEAD == 2 && !BWD;       // downsample branch computed in phase 3
   constexpr int ROWB = 128;                    // H1 / H2 / conv2 / conv3 weight rows: 64 channels
   // ---- LDS map (80 KB; two workgroups per CU) ----
   // phase 1: ring of four 32-channel K-steps, S(s) = s * 16384: X[192 rows][64 B] (12 KB) + W1[64 rows][64 B] (4 KB)
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   // head, forward: the downsample branch (both passes' addends) is requested first of all — it returns with the first
   // K-step; anywhere later it would sit behind LDS-DMA batches whose counted waits it must not disturb
   bf16x8_t ad0[4][2], ad1[4][2];
-  if constexpr (HEAD && !BWD) {
+  if constexpr (HEAD && !BWD && !DSK) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int y = y0 + wm * 4 + j, x = x0 + fr;
@@ -486,13 +494,29 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   if constexpr (KS1 == 8) lds_barrier();   // b2: [65536, 81920) is free
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and taps 2..5 have landed
   BLK_STAMP(5);
+  f32x4_t sc2v[2], sh2v[2];
+  if constexpr (DSK) {   // requested a barrier early and touched right behind b3's vmcnt(0): see below
+#pragma unroll
+    for (int i = 0; i < 2; ++i) load_affine(p.sc2, p.sh2, cb8 + 4 * i, sc2v[i], sh2v[i]);
+  }
   load_tap(7);
   load_tap(8);
 #pragma unroll
   for (int t = 2; t < 7; ++t) tap_compute(t);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // b3: taps 7, 8 landed; [0, 40960) is free
   BLK_STAMP(6);
+  // (the compiler waits vmcnt(0) where a load it knows about is first used; with the operands of epilogue 2 touched
+  // here that wait coincides with b3's instead of draining the transfers issued at b3 / b4)
+  if constexpr (DSK) asm volatile("" ::"v"(sc2v[0]), "v"(sc2v[1]), "v"(sh2v[0]), "v"(sh2v[1]));
   // conv3 weights [4C][C] into [0, 32768) while taps 7 and 8 are multiplied
+  // rows n0 .. n0 + 8 * ngroups of a [rows][C] weight matrix (16 channels per lane: swz_w16) to smem + base
+  auto load_wrows = [&](const bf16_t* w, int n0, int ngroups, int base) {
+#pragma unroll
+    for (int g8 = wave; g8 < ngroups; g8 += 4) {
+      const int n = n0 + g8 * 8 + lrow8;
+      glds16_async((const char*)w + (int64_t)n * C * 2 + ((lchunk8 ^ swz_w16(n)) * 16), smem + base + g8 * 8 * ROWB);
+    }
+  };
   if constexpr (BWD && HEAD) {   // [C][C]: one tap's worth, in the taps' layout
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -500,6 +524,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       const int n = g8 * 8 + lrow8;
       glds16_async((const char*)p.w3 + (int64_t)n * C * 2 + ((lchunk8 ^ swz_w8(n)) * 16), smem + W3_OFF + g8 * 8 * ROWB);
     }
+  } else if constexpr (DSK) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {      // X2: pixel row pr = 16 * tile row + tile column, chunk swizzle (pr >> 1) & 7
+      const int g8 = it * 4 + wave;
+      const int pr = g8 * 8 + lrow8;
+      const int y = y0 + (pr >> 4), x = x0 + (pr & 15);
+      const char* src = ((y < H) && (x < W))
+                            ? (const char*)p.a + ((img_pix0 + (int64_t)y * W + x) * C + ((lchunk8 ^ ((pr >> 1) & 7)) * 8)) * 2
+                            : (const char*)g_zero_page + lchunk8 * 16;
+      glds16_async(src, smem + g8 * 8 * ROWB);
+    }
+    load_wrows(p.wd, 0, 16, 16384);
+    load_wrows(p.w3, 0, 8, 32768);
   } else {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -508,13 +545,18 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       glds16_async((const char*)p.w3 + (int64_t)n * C * 2 + ((lchunk8 ^ swz_w16(n)) * 16), smem + W3_OFF + g8 * 8 * ROWB);
     }
   }
-  f32x4_t sc2v[2], sh2v[2];
+  if constexpr (!DSK) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) load_affine(p.sc2, p.sh2, cb8 + 4 * i, sc2v[i], sh2v[i]);
+    for (int i = 0; i < 2; ++i) load_affine(p.sc2, p.sh2, cb8 + 4 * i, sc2v[i], sh2v[i]);
+  }
   tap_compute(7);
   tap_compute(8);
   lds_barrier();   // b4: every wave is done with H1
   BLK_STAMP(7);
+  if constexpr (DSK) {
+    load_wrows(p.w3, 64, 8, 57344);
+    load_wrows(p.wd, 128, 16, 65536);
+  }
   bf16x8_t o2v[4];
   unsigned b2w[4];
   f32x4_t sc3v[4], sh3v[4];
@@ -555,9 +597,32 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, chw + 4 * i, sc3v[i], sh3v[i]);
+  f32x4_t scdv[DSK ? 4 : 1], shdv[DSK ? 4 : 1];
+  if constexpr (DSK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_affine(p.scd, p.shd, chw + 4 * i, scdv[i], shdv[i]);
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // b5: H2 complete, conv3 weights landed
 
   BLK_STAMP(8);
+  auto store_o2 = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + wm * 4 + j, x = x0 + pi;
+      const bool ok = (y < H) && (x < W);
+      const int64_t pix = img_pix0 + (int64_t)y * W + x;
+      *(bf16x8_t*)(ok ? p.o2 + pix * C + cb8 : (bf16_t*)g_blk_sink) = o2v[j];
+    }
+    if constexpr (!BWD) {
+      if (p.b2) {   // h2 > 0 words: lane fq stores tile row wm * 4 + fq's word of its pixel column
+        const int y = y0 + wm * 4 + fq, x = x0 + pi;
+        *((y < H && x < W) ? p.b2 + (img_pix0 + (int64_t)y * W + x) * (C / 32) + wn : (unsigned*)g_blk_sink) =
+            sel4(b2w[0], b2w[1], b2w[2], b2w[3]);
+      }
+    }
+  };
+  // downsample branch computed here: no load is in flight behind b5, so h2 leaves at once (and frees its registers)
+  if constexpr (DSK) store_o2();
   // ================= phase 3: OUT[8x16][4C], two passes of 128 channels =================
   const int wrow16 = (wn * 64 + (fr >> 2) * 16 + (fr & 3)) * ROWB;   // + 4i rows: 16 consecutive channels per lane
   if constexpr (BWD && HEAD) {
@@ -605,12 +670,51 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
 #pragma unroll
     for (int nc = 0; nc < 2; ++nc) {
       __builtin_amdgcn_sched_barrier(0);   // keep the passes apart: hoisting the second one's loads and MFMAs spills
+      bf16x8_t rd[DSK ? 4 : 1][2];     // the downsample branch of this pass, as the separate launch would have stored it
+      if constexpr (DSK) {
+        f32x4_t accd[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) accd[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const char* sWd = smem + (nc == 0 ? 16384 : 65536) + wrow16;
+        const char* sXd = smem + (wm * 64 + fr) * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8_t wf[4], xf[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wf[i] = lds_read_b128(sWd + i * 4 * ROWB + (((kk * 4 + fq) ^ f_rd_w) * 16));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xf[j] = lds_read_b128(sXd + j * 16 * ROWB + (((kk * 4 + fq) ^ f_rd) * 16));
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accd[i][j] = mfma16<F16>(wf[i], xf[j], accd[i][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              rd[j][h][e] = f32_to_elem<F16>((accd[2 * h][j] * scdv[2 * h] + shdv[2 * h])[e]);
+              rd[j][h][4 + e] = f32_to_elem<F16>((accd[2 * h + 1][j] * scdv[2 * h + 1] + shdv[2 * h + 1])[e]);
+            }
+        if (nc == 0) {
+          lds_barrier();                       // b6: the first pass's downsample rows are consumed
+          load_wrows(p.w3, 128, 16, 16384);    // conv3 rows 128..255 take their place
+        } else {
+          // b7: those rows have landed — behind them this wave has issued the first pass's 8 stores
+          asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+      }
       f32x4_t acc3[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc3[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const char* sW = smem + W3_OFF + nc * 128 * ROWB + wrow16;
+      const char* sW = !DSK ? smem + W3_OFF + nc * 128 * ROWB + wrow16
+                            : (nc == 0 ? smem + (wn ? 57344 : 32768) + ((fr >> 2) * 16 + (fr & 3)) * ROWB : smem + 16384 + wrow16);
       const char* sX = smem + H2_OFF + (wm * 64 + fr) * ROWB;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -634,8 +738,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[2 * h][e] += elem_to_f32<F16>((nc == 0 ? ad0 : ad1)[j][h][e]);
-            v[2 * h + 1][e] += elem_to_f32<F16>((nc == 0 ? ad0 : ad1)[j][h][4 + e]);
+            v[2 * h][e] += elem_to_f32<F16>((DSK ? rd[DSK ? j : 0] : (nc == 0 ? ad0 : ad1)[j])[h][e]);
+            v[2 * h + 1][e] += elem_to_f32<F16>((DSK ? rd[DSK ? j : 0] : (nc == 0 ? ad0 : ad1)[j])[h][4 + e]);
           }
         if constexpr (BWD) {
           // this lane's 16 mask bits of the pixel (bit 8h + e: element e of half h); no mask at all: all ones
@@ -667,22 +771,24 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       __builtin_amdgcn_sched_barrier(0);
       if (nc == 0) {   // the second pass's operands travel while the first pass's results are stored
         if constexpr (BWD && !MB) { load_ad(1, ad1); load_mask3(1); }
+        int ch1 = 128 + chw;
+        // (16 loads = 64 registers when the downsample branch is computed here.  The opaque definition keeps them from
+        // being hoisted into the GEMM above, the opaque uses keep the epilogue from being sunk below them: either way
+        // they would be live together with the accumulators, and spill)
+        if constexpr (DSK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, 128 + chw + 4 * i, sc3v[i], sh3v[i]);
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {   // h2 / g1 to HBM: behind every load a later wait counts
-          const int y = y0 + wm * 4 + j, x = x0 + pi;
-          const bool ok = (y < H) && (x < W);
-          const int64_t pix = img_pix0 + (int64_t)y * W + x;
-          *(bf16x8_t*)(ok ? p.o2 + pix * C + cb8 : (bf16_t*)g_blk_sink) = o2v[j];
+            for (int h = 0; h < 2; ++h) asm volatile("" ::"v"(ov[j][h]));
+          asm volatile("" : "+v"(ch1));
         }
-        if constexpr (!BWD) {
-          if (p.b2) {   // h2 > 0 words: lane fq stores tile row wm * 4 + fq's word of its pixel column
-            const int y = y0 + wm * 4 + fq, x = x0 + pi;
-            *((y < H && x < W) ? p.b2 + (img_pix0 + (int64_t)y * W + x) * (C / 32) + wn : (unsigned*)g_blk_sink) =
-                sel4(b2w[0], b2w[1], b2w[2], b2w[3]);
-          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_affine(p.sc3, p.sh3, ch1 + 4 * i, sc3v[i], sh3v[i]);
+        if constexpr (DSK) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) load_affine(p.scd, p.shd, ch1 + 4 * i, scdv[i], shdv[i]);
         }
+        if constexpr (!DSK) store_o2();   // h2 / g1 to HBM: behind every load a later wait counts
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -1237,7 +1343,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-template <bool BWD, bool F16, bool MB = false, bool HEAD = false>
+template <bool BWD, bool F16, bool MB = false, int HEAD = 0>
 static int launch_block64(BlockParams& p, hipStream_t stream) {
   constexpr int lds = 81920;
   static tdn_attr_once attr_once;
@@ -1347,13 +1453,19 @@ extern "C" int tdn_bottleneck_head_fwd(const tdn_bottleneck_head_args* a, int dt
   TDN_CHECK(a != nullptr, "bottleneck head: NULL argument block");
   if (block_common(p, &a->b, dtype)) return -1;
   TDN_CHECK(a->b.C == 64, "bottleneck head: C=%d is not built (64)", a->b.C);
-  TDN_CHECK(a->addend != nullptr, "bottleneck head fwd: the downsample branch (addend) is required");
+  TDN_CHECK((a->addend != nullptr) != (a->wd != nullptr),
+            "bottleneck head fwd: give either the downsample branch (addend) or its weights (wd), not both / neither");
   TDN_CHECK(a->b.bits3 == nullptr, "bottleneck head fwd: there is no bits3 plane (the block input is not masked)");
   p.sc1 = a->b.scale1; p.sh1 = a->b.shift1; p.sc2 = a->b.scale2; p.sh2 = a->b.shift2; p.sc3 = a->b.scale3; p.sh3 = a->b.shift3;
   p.b1 = (unsigned*)a->b.bits1; p.b2 = (unsigned*)a->b.bits2;
   p.ad = (const bf16_t*)a->addend;
-  if (dtype == TDN_F16) return launch_block64<false, true, false, true>(p, (hipStream_t)stream);
-  return launch_block64<false, false, false, true>(p, (hipStream_t)stream);
+  if (a->wd) {
+    p.wd = (const bf16_t*)a->wd; p.scd = a->scale_d; p.shd = a->shift_d;
+    if (dtype == TDN_F16) return launch_block64<false, true, false, 2>(p, (hipStream_t)stream);
+    return launch_block64<false, false, false, 2>(p, (hipStream_t)stream);
+  }
+  if (dtype == TDN_F16) return launch_block64<false, true, false, 1>(p, (hipStream_t)stream);
+  return launch_block64<false, false, false, 1>(p, (hipStream_t)stream);
 }
 
 extern "C" int tdn_bottleneck_head_dgrad(const tdn_bottleneck_head_args* a, int dtype, void* stream) {
@@ -1361,16 +1473,17 @@ extern "C" int tdn_bottleneck_head_dgrad(const tdn_bottleneck_head_args* a, int 
   TDN_CHECK(a != nullptr, "bottleneck head: NULL argument block");
   if (block_common(p, &a->b, dtype)) return -1;
   TDN_CHECK(a->b.C == 64, "bottleneck head: C=%d is not built (64)", a->b.C);
-  TDN_CHECK(a->addend != nullptr, "bottleneck head dgrad: the downsample branch's input gradient (addend) is required");
+  TDN_CHECK(a->addend != nullptr && a->wd == nullptr,
+            "bottleneck head dgrad: the downsample branch's input gradient (addend) is required; wd is a forward operand");
   TDN_CHECK(a->b.mask3 == nullptr && a->b.bits3 == nullptr, "bottleneck head dgrad: the block input gradient takes no mask");
   p.m1 = (const bf16_t*)a->b.mask1; p.m2 = (const bf16_t*)a->b.mask2;
   p.b1 = (unsigned*)a->b.bits1; p.b2 = (unsigned*)a->b.bits2;
   p.ad = (const bf16_t*)a->addend;
   if (a->b.bits1 || a->b.bits2) {
     TDN_CHECK(a->b.bits1 && a->b.bits2, "bottleneck head dgrad: both bit planes or none");
-    if (dtype == TDN_F16) return launch_block64<true, true, true, true>(p, (hipStream_t)stream);
-    return launch_block64<true, false, true, true>(p, (hipStream_t)stream);
+    if (dtype == TDN_F16) return launch_block64<true, true, true, 1>(p, (hipStream_t)stream);
+    return launch_block64<true, false, true, 1>(p, (hipStream_t)stream);
   }
-  if (dtype == TDN_F16) return launch_block64<true, true, false, true>(p, (hipStream_t)stream);
-  return launch_block64<true, false, false, true>(p, (hipStream_t)stream);
+  if (dtype == TDN_F16) return launch_block64<true, true, false, 1>(p, (hipStream_t)stream);
+  return launch_block64<true, false, false, 1>(p, (hipStream_t)stream);
 }

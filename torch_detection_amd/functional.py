@@ -836,7 +836,8 @@ def _block_fusable(b, C4):
 def _block_head_fusable(b, Cin):
     """The stage's first Bottleneck where it keeps the resolution (layer1.0, resnet.py:130-136: a 1x1 conv + BN
     downsample because inplanes != 4 * planes): conv1 -> conv2 -> conv3 + residual run as one launch whose residual is
-    the downsample branch, computed by a launch of its own (ops.bottleneck_head_fwd / _dgrad).  TDN_BLOCK_HEAD=0 (or
+    the downsample branch — computed inside the forward launch (default, TDN_BLOCK_HEAD=2) or by a launch of its own
+    (TDN_BLOCK_HEAD=1; always so in the backward pass: ops.bottleneck_head_fwd / _dgrad).  TDN_BLOCK_HEAD=0 (or
     TDN_BLOCK_FUSE=0) keeps the per-conv launches."""
     if b.kind != 'bottleneck' or b.ud is None or b.stride != 1:
         return False
@@ -886,12 +887,16 @@ def _block_fwd(x, b, bufs=None):
         return out, (x, h1, h2, out)
     if _block_head_fusable(b, x.shape[3]):
         u1, u2, u3 = b.u1, b.u2, b.u3
-        res = unit_fwd(b.ud, x, relu=False, out=ores)
+        down = None
+        if os.environ.get('TDN_BLOCK_HEAD', '2') == '1':
+            res = unit_fwd(b.ud, x, relu=False, out=ores)
+        else:
+            res, down = None, (b.ud.w_fwd, b.ud.scale, b.ud.shift)
         if bufs is None and _block_bits_on() and _WANT_BWD[0]:
             bits = ops.bottleneck_bit_planes(x.shape[0], x.shape[1], x.shape[2], u1.Cout, x.device)[:2]
         h1, h2, out = ops.bottleneck_head_fwd(x, u1.w_fwd, u2.w_fwd, u3.w_fwd,
                                               (u1.scale, u1.shift, u2.scale, u2.shift, u3.scale, u3.shift), res,
-                                              outs=(o1, o2, o3) if bufs is not None else None, bits=bits)
+                                              outs=(o1, o2, o3) if bufs is not None else None, bits=bits, down=down)
         if bufs is None and bits is not None:
             h1._tdn_bits = bits
         return out, (x, h1, h2, out)
@@ -962,7 +967,9 @@ def _blocks_fwd_split(blocks, cur):
                      ops.conv_out_size(W, b.u1.k, b.u1.stride, b.u1.pad), b.u1.Cout)
             h2 = None
             out = new(h1.shape[1], h1.shape[2], b.u2.Cout)
-        res = new(out.shape[1], out.shape[2], out.shape[3]) if b.ud is not None else None
+        res = None
+        if b.ud is not None and not (_block_head_fusable(b, x.shape[3]) and os.environ.get('TDN_BLOCK_HEAD', '2') != '1'):
+            res = new(out.shape[1], out.shape[2], out.shape[3])     # (a head block computes the branch in its launch)
         bits = None
         if _block_bits_on() and _WANT_BWD[0] and _block_fusable(b, x.shape[3]):
             bits = ops.bottleneck_bit_planes(N, H, W, b.u1.Cout, dev)

@@ -358,14 +358,29 @@ def _head_args(args, addend, shape, dtype, name):
     return h
 
 
-def bottleneck_head_fwd(x, w1, w2, w3, affine, res, outs=None, bits=None):
+def bottleneck_head_fwd(x, w1, w2, w3, affine, res=None, outs=None, bits=None, down=None):
     """First Bottleneck of layer1 (resnet.py:130-136: 1x1 downsample because inplanes != 4 * planes; stride 1) in one
-    launch: x [N,H,W,C], ``res`` [N,H,W,4C] = the downsample branch (conv + BN, a launch of its own); returns
-    (h1, h2, out) with out = relu(bn3(conv3(h2)) + res).  ``bits`` = optional (b1, b2) planes."""
+    launch: x [N,H,W,C]; returns (h1, h2, out) with out = relu(bn3(conv3(h2)) + downsample(x)).  The downsample
+    branch is either ``res`` [N,H,W,4C] (conv + BN, a launch of its own) or computed inside the launch from
+    ``down`` = (w_fwd [4C,1,1,C], scale, shift).  ``bits`` = optional (b1, b2) planes."""
     N, H, W, C = x.shape
+    if (res is None) == (down is None):
+        raise ValueError("bottleneck_head_fwd: give either res or down")
     bits3 = (bits[0], bits[1], None) if bits is not None else None
     args, o = _bottleneck_args("bottleneck_head_fwd", x, w1, w2, w3, affine, None, outs, bits3, head='fwd')
-    h = _head_args(args, res, (N, H, W, 4 * C), x.dtype, "bottleneck_head_fwd")
+    if res is not None:
+        h = _head_args(args, res, (N, H, W, 4 * C), x.dtype, "bottleneck_head_fwd")
+    else:
+        wd, scd, shd = down
+        if wd.dtype != x.dtype or tuple(wd.shape) != (4 * C, 1, 1, C) or not wd.is_contiguous() or not wd.is_cuda:
+            raise ValueError("bottleneck_head_fwd: downsample weights must be %s %s contiguous" % (x.dtype, (4 * C, 1, 1, C)))
+        h = _lib.BottleneckHeadArgs()
+        h.b = args
+        h.wd = wd.data_ptr()
+        for fld, v in (("scale_d", scd), ("shift_d", shd)):
+            if v is not None:
+                _chk_vec(v, fld, 4 * C)
+                setattr(h, fld, v.data_ptr())
     _lib.check(_lib.load().tdn_bottleneck_head_fwd(ctypes.byref(h), dtype_code(x.dtype), _lib.stream_ptr()),
                "tdn_bottleneck_head_fwd")
     return o
