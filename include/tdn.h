@@ -246,9 +246,10 @@ int tdn_bottleneck_dgrad(const tdn_bottleneck_args* a, int dtype, void* stream);
 typedef struct tdn_bottleneck_head_args {
   tdn_bottleneck_args b;
   const void* addend;
-  /* forward only, INSTEAD of addend: the downsample conv's w_fwd [4C][1][1][Cin] and folded BN [4C] (NULL = 1 / 0) —
-   * the branch is then computed inside the launch (same K order, affine and 16-bit rounding as its own launch would
-   * apply, so the result is still bit-identical) and never travels through HBM */
+  /* INSTEAD of addend: the downsample conv's own operands — forward: w_fwd [4C][1][1][Cin] and folded BN [4C]
+   * (NULL = 1 / 0); dgrad: w_dgrad [Cin][1][1][4C] (scale_d / shift_d unused).  The branch is then computed inside the
+   * launch (same K order, affine and 16-bit rounding as its own launch would apply: still bit-identical) and never
+   * travels through HBM */
   const void* wd;
   const float* scale_d; const float* shift_d;
 } tdn_bottleneck_head_args;

@@ -310,3 +310,13 @@ def test_head_block_forward_and_dgrad(ops, generic_tiles, N, H, W, dtype, with_b
         ne = a.view(torch.int16) != b.view(torch.int16)
         assert not bool(ne.any()), "%s: %d of %d elements differ, first %s" % (name, int(ne.sum()), a.numel(), ne.nonzero()[:4].tolist())
     assert dx.shape == (N, H, W, C)
+    # the same with the downsample conv's input gradient computed inside the launch
+    if with_bits:
+        k2, k1, kx = ops.bottleneck_head_dgrad(g, w3d, w2d, w1d, None, None, bits=bits, down=wdd)
+    else:
+        k2, k1, kx = ops.bottleneck_head_dgrad(g, w3d, w2d, w1d, (h2, h1), None, down=wdd)
+    torch.cuda.synchronize()
+    for name, a, b in (("g2", k2, q2), ("g1", k1, q1), ("dx", kx, qx)):
+        ne = a.view(torch.int16) != b.view(torch.int16)
+        assert not bool(ne.any()), "in-launch downsample, %s: %d of %d elements differ, first %s" % (
+            name, int(ne.sum()), a.numel(), ne.nonzero()[:4].tolist())

@@ -140,10 +140,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   constexpr int CA = (HEAD && !BWD) ? C : C4;   // channels of p.a = K of phase 1
   constexpr int KS1 = CA / 32;
   constexpr bool DSK = HEAD == 2 && !BWD;       // downsample branch computed in phase 3
+  // HEAD == 2, backward: the downsample conv's input gradient t = Wd^T . g is accumulated in phase 1 beside conv3's
+  // (same operand stream g, a second weight chunk per K-step and a second accumulator set, over the haloed patch like
+  // the first), rounded to 16 bit as its own launch would store it, parked in registers through phase 2, handed to
+  // phase 3's pixel layout through a [128 pixels][C] LDS tile at [8192, 24576), and added there.  The ring then has
+  // three slots of 20 KB (X 12 KB + two weight chunks of 4 KB); taps 2, 3 are issued at the last K-step, 4..6 behind b0.
+  constexpr bool DSB = HEAD == 2 && BWD;
   constexpr int ROWB = 128;                    // H1 / H2 / conv2 / conv3 weight rows: 64 channels
   // ---- LDS map (80 KB; two workgroups per CU) ----
   // phase 1: ring of four 32-channel K-steps, S(s) = s * 16384: X[192 rows][64 B] (12 KB) + W1[64 rows][64 B] (4 KB)
-  constexpr int SLOT = 16384, XB32 = PHP * 64;
+  constexpr int SLOT = DSB ? 20480 : 16384, NSLOT = DSB ? 3 : 4, XB32 = PHP * 64;
   constexpr int T_OFF = 65536;                 // conv2 taps 0, 1 (issued at kernel start), later taps 7, 8
   constexpr int TAP_BYTES = C * ROWB;          // 8192
   // conv2 taps 2..6 at [0, 40960): issued into the ring slots as phase 1 releases them (they take the place of the
@@ -211,12 +217,18 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     const int n = wave * 16 + lrow16;
     w1src = (const char*)p.w1 + ((int64_t)n * CA) * 2 + ((lchunk4 ^ ((4 - ((n >> 3) & 3)) & 3)) * 16);
   }
-  auto load_step = [&](int kc) {   // K-step kc (32 channels) into ring slot kc & 3
-    char* sX = smem + (kc & 3) * SLOT;
+  const char* wdsrc = nullptr;
+  if constexpr (DSB) {
+    const int n = wave * 16 + lrow16;
+    wdsrc = (const char*)p.wd + ((int64_t)n * CA) * 2 + ((lchunk4 ^ ((4 - ((n >> 3) & 3)) & 3)) * 16);
+  }
+  auto load_step = [&](int kc) {   // K-step kc (32 channels) into ring slot kc % NSLOT
+    char* sX = smem + (kc % NSLOT) * SLOT;
 #pragma unroll
     for (int it = 0; it < 3; ++it)
       glds16_async((xok >> it) & 1u ? xsrc[it] + kc * 64 : zero, sX + (it * 4 + wave) * 1024);
     glds16_async(w1src + kc * 64, sX + XB32 + wave * 1024);
+    if constexpr (DSB) glds16_async(wdsrc + kc * 64, sX + XB32 + 4096 + wave * 1024);
   };
 
   // ---- fragment read constants ----
@@ -256,8 +268,31 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     }
   }
 
+  // backward: mask operands of the phase 2 epilogue (requested behind b1; before the K loop when the ring is followed
+  // by tap transfers whose counted waits they must not disturb: DSB)
+  bf16x8_t mk2[MB ? 1 : 4];
+  unsigned mw2[MB ? 4 : 1];
+  auto load_mask2 = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + wm * 4 + j, x = x0 + pi;
+      const bool ok = (y < H) && (x < W);
+      const int64_t pix = img_pix0 + (int64_t)y * W + x;
+      if constexpr (MB) mw2[j] = *(ok ? p.b1 + pix * (C / 32) + wn : (const unsigned*)g_blk_zero);
+      else mk2[j] = (p.m2 && ok) ? *(const bf16x8_t*)(p.m2 + pix * C + cb8) : bf16x8_t{};
+    }
+  };
+  if constexpr (DSB) load_mask2();
+
   // ================= phase 1: H1[halo][C], eight 32-deep K-steps through a four-slot ring =================
   f32x4_t acc1[2][6];
+  f32x4_t acct[DSB ? 2 : 1][DSB ? 6 : 1];
+  if constexpr (DSB) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acct[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -280,7 +315,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   }
   load_step(0);
   load_step(1);
-  if constexpr (KS1 == 8) load_step(2);
+  if constexpr (DSB) {}
+  else if constexpr (KS1 == 8) load_step(2);
   else load_tap(6);       // [32768, 40960): the third ring slot, which two K-steps never use
 #pragma unroll
   for (int kc = 0; kc < KS1; ++kc) {
@@ -289,7 +325,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     // lgkmcnt(0): with the loop unrolled the scheduler sinks the MFMAs — and the waits of their fragment reads — below
     // the barrier; a read still queued in the LDS pipe can then be overtaken by the LDS-DMA another wave issues into
     // the same ring slot right behind the barrier (seen: 1 KiB pieces of stale data in ~10 of 525 tiles per launch)
-    if constexpr (KS1 == 8) {
+    if constexpr (DSB) {   // three slots: one K-step (5 instructions per wave) in flight behind K-step kc
+      if (kc < 7) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if constexpr (KS1 == 8) {
       asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // K-step kc landed; slot (kc - 1) & 3 is free
     } else {      // two K-steps: behind K-step 0 are K-step 1 (4 instructions per wave) and tap 6 (2)
       if (kc == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -297,14 +336,27 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     }
     if (kc == 0) BLK_STAMP(1);
     if (kc == 4) BLK_STAMP(2);
-    if constexpr (KS1 == 8) {
+    if constexpr (DSB) {
+      if (kc + 2 < 8) load_step(kc + 2);
+      else if (kc == 7) {
+        // taps 2, 3 into slot 0 (read last at K-step 6).  The epilogues' mask operands are touched first: everything
+        // issued so far has landed (vmcnt(0) above), so the compiler's own wait for them costs nothing here — behind
+        // the tap transfers it would drain them
+        if constexpr (MB) {
+          asm volatile("" ::"v"(mw1[0]), "v"(mw1[MB ? 5 : 0]), "v"(mw2[0]), "v"(mw2[MB ? 3 : 0]));
+        } else {
+          asm volatile("" ::"v"(mk1[0]), "v"(mk1[MB ? 0 : 5]), "v"(mk2[0]), "v"(mk2[MB ? 0 : 3]));
+        }
+        load_tap(2); load_tap(3);
+      }
+    } else if constexpr (KS1 == 8) {
       if (kc + 3 < 8) load_step(kc + 3);
       else if (kc == 5) { load_tap(2); load_tap(3); }
       else if (kc == 6) { load_tap(4); load_tap(5); }
       else { load_tap(6); }
     }
-    const char* sX = smem + (kc & 3) * SLOT + (wm * 96 + fr) * 64 + ((fq ^ f_rd32) * 16);
-    const char* sW = smem + (kc & 3) * SLOT + XB32 + wrow8 * 64 + ((fq ^ f_rd32) * 16);
+    const char* sX = smem + (kc % NSLOT) * SLOT + (wm * 96 + fr) * 64 + ((fq ^ f_rd32) * 16);
+    const char* sW = smem + (kc % NSLOT) * SLOT + XB32 + wrow8 * 64 + ((fq ^ f_rd32) * 16);
     bf16x8_t wf[2], xf[6];
 #pragma unroll
     for (int i = 0; i < 2; ++i) wf[i] = lds_read_b128(sW + i * 4 * 64);
@@ -314,9 +366,29 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 6; ++j) acc1[i][j] = mfma16<F16>(wf[i], xf[j], acc1[i][j]);
+    if constexpr (DSB) {
+      bf16x8_t wt[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wt[i] = lds_read_b128(sW + 4096 + i * 4 * 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acct[i][j] = mfma16<F16>(wt[i], xf[j], acct[i][j]);
+    }
   }
   lds_barrier();   // b0: every wave is done reading the ring
   BLK_STAMP(3);
+  bf16x8_t tpk[DSB ? 6 : 1];   // DSB: t of this lane's six patch pixels (its 8 channels), as the downsample dgrad launch stores it
+  if constexpr (DSB) {
+    load_tap(4); load_tap(5); load_tap(6);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tpk[j][e] = f32_to_elem<F16>(acct[0][j][e] * 1.f + 0.f);
+        tpk[j][4 + e] = f32_to_elem<F16>(acct[1][j][e] * 1.f + 0.f);
+      }
+  }
   if constexpr (KS1 != 8) {
     // taps 2..5 go where the two K-steps were.  The epilogue's affine operands are touched first: the compiler waits
     // vmcnt(0) at the first use of a load it knows about, which must not fall behind these eight instructions
@@ -368,19 +440,23 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   }
   // b1: H1 complete (LDS writes of every wave), taps 2..6 landed (taps 0 / 1 long ago); two K-steps: taps 2..5 (eight
   // instructions per wave) are still travelling and are waited for at b2
-  if constexpr (KS1 == 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (DSB) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // taps 2..6 travel on
+  else if constexpr (KS1 == 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   BLK_STAMP(4);
-  // h1 / g2 to HBM: behind the barrier, so that nobody waits for the stores
+  // h1 / g2 to HBM: behind the barrier, so that nobody waits for the stores (DSB: behind b2, which drains the queue)
+  auto store_o1 = [&]() {
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    if ((st1 >> j) & 1u) {
-      const int R = wm * 96 + j * 16 + fr;
-      const int hy = R / HWD, hx = R - hy * HWD;
-      const int64_t pix = img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx);
-      *(bf16x8_t*)(p.o1 + pix * C + cb8) = o1v[j];
+    for (int j = 0; j < 6; ++j) {
+      if ((st1 >> j) & 1u) {
+        const int R = wm * 96 + j * 16 + fr;
+        const int hy = R / HWD, hx = R - hy * HWD;
+        const int64_t pix = img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx);
+        *(bf16x8_t*)(p.o1 + pix * C + cb8) = o1v[j];
+      }
     }
-  }
+  };
+  if constexpr (!DSB) store_o1();
   if constexpr (!BWD) {
     if (p.b1) {   // h1 > 0 words: lane fq stores fragment fq's (then fragment 4 + fq's) word of its pixel column
 #pragma unroll
@@ -395,19 +471,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       }
     }
   }
-  // backward: mask operands of the phase 2 epilogue
-  bf16x8_t mk2[MB ? 1 : 4];
-  unsigned mw2[MB ? 4 : 1];
-  if constexpr (BWD) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int y = y0 + wm * 4 + j, x = x0 + pi;
-      const bool ok = (y < H) && (x < W);
-      const int64_t pix = img_pix0 + (int64_t)y * W + x;
-      if constexpr (MB) mw2[j] = *(ok ? p.b1 + pix * (C / 32) + wn : (const unsigned*)g_blk_zero);
-      else mk2[j] = (p.m2 && ok) ? *(const bf16x8_t*)(p.m2 + pix * C + cb8) : bf16x8_t{};
-    }
-  }
+  if constexpr (BWD && !DSB) load_mask2();
 
   // Phase 3's per-pixel operands are requested HERE, a whole phase ahead: loads return in issue order, so behind a
   // batch of LDS-DMA they would not be back before it has landed, and their first use sits behind b3 / b5, where the
@@ -448,9 +512,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   };
   bf16x8_t adh[(BWD && HEAD) ? 4 : 1];   // head, backward: this lane's 8 channels of the downsample branch's input gradient
   if constexpr (BWD && HEAD) {
+    if constexpr (!DSB) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      adh[j] = *(const bf16x8_t*)(pixj[j] >= 0 ? p.ad + (int64_t)pixj[j] * C + cb8 : (const bf16_t*)g_blk_zero);
+      for (int j = 0; j < 4; ++j)
+        adh[j] = *(const bf16x8_t*)(pixj[j] >= 0 ? p.ad + (int64_t)pixj[j] * C + cb8 : (const bf16_t*)g_blk_zero);
+    }
   } else if constexpr (!HEAD) {
     load_ad(0, ad0);
     if constexpr (BWD && !MB) load_mask3(0);
@@ -491,9 +557,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   };
   tap_compute(0);
   tap_compute(1);
-  if constexpr (KS1 == 8) lds_barrier();   // b2: [65536, 81920) is free
-  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and taps 2..5 have landed
+  if constexpr (KS1 == 8 && !DSB) lds_barrier();   // b2: [65536, 81920) is free
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and taps 2..5 (DSB: 2..6) have landed
   BLK_STAMP(5);
+  if constexpr (DSB) store_o1();
   f32x4_t sc2v[2], sh2v[2];
   if constexpr (DSK) {   // requested a barrier early and touched right behind b3's vmcnt(0): see below
 #pragma unroll
@@ -517,6 +584,18 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
       glds16_async((const char*)w + (int64_t)n * C * 2 + ((lchunk8 ^ swz_w16(n)) * 16), smem + base + g8 * 8 * ROWB);
     }
   };
+  constexpr int TD_OFF = 8192;
+  if constexpr (DSB) {   // t of the tile's interior pixels to [TD_OFF, TD_OFF + 16384), rows in H2's layout
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if ((st1 >> j) & 1u) {
+        const int R = wm * 96 + j * 16 + fr;
+        const int hy = R / HWD, hx = R - hy * HWD;
+        const int pr = (hy - 1) * TW + (hx - 1);
+        *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + TD_OFF + pr * ROWB + (((wn * 4 + fq) ^ ((pr >> 1) & 7)) * 16)) = tpk[j];
+      }
+    }
+  }
   if constexpr (BWD && HEAD) {   // [C][C]: one tap's worth, in the taps' layout
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -627,6 +706,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_kernel(const BlockParams 
   const int wrow16 = (wn * 64 + (fr >> 2) * 16 + (fr & 3)) * ROWB;   // + 4i rows: 16 consecutive channels per lane
   if constexpr (BWD && HEAD) {
     // dx[8x16][C] = W1d[C][C] . G1 + (downsample branch's input gradient): one pass in the shape of a conv2 tap
+    if constexpr (DSB) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pr = (wm * 4 + j) * TW + fr;
+        adh[j] = lds_read_b128(smem + TD_OFF + pr * ROWB + (((wn * 4 + fq) ^ ((pr >> 1) & 7)) * 16));
+      }
+    }
     f32x4_t acc3[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1473,16 +1559,25 @@ extern "C" int tdn_bottleneck_head_dgrad(const tdn_bottleneck_head_args* a, int 
   TDN_CHECK(a != nullptr, "bottleneck head: NULL argument block");
   if (block_common(p, &a->b, dtype)) return -1;
   TDN_CHECK(a->b.C == 64, "bottleneck head: C=%d is not built (64)", a->b.C);
-  TDN_CHECK(a->addend != nullptr && a->wd == nullptr,
-            "bottleneck head dgrad: the downsample branch's input gradient (addend) is required; wd is a forward operand");
+  TDN_CHECK((a->addend != nullptr) != (a->wd != nullptr),
+            "bottleneck head dgrad: give either the downsample conv's input gradient (addend) or its w_dgrad (wd)");
   TDN_CHECK(a->b.mask3 == nullptr && a->b.bits3 == nullptr, "bottleneck head dgrad: the block input gradient takes no mask");
   p.m1 = (const bf16_t*)a->b.mask1; p.m2 = (const bf16_t*)a->b.mask2;
   p.b1 = (unsigned*)a->b.bits1; p.b2 = (unsigned*)a->b.bits2;
   p.ad = (const bf16_t*)a->addend;
+  p.wd = (const bf16_t*)a->wd;
   if (a->b.bits1 || a->b.bits2) {
     TDN_CHECK(a->b.bits1 && a->b.bits2, "bottleneck head dgrad: both bit planes or none");
+    if (a->wd) {
+      if (dtype == TDN_F16) return launch_block64<true, true, true, 2>(p, (hipStream_t)stream);
+      return launch_block64<true, false, true, 2>(p, (hipStream_t)stream);
+    }
     if (dtype == TDN_F16) return launch_block64<true, true, true, 1>(p, (hipStream_t)stream);
     return launch_block64<true, false, true, 1>(p, (hipStream_t)stream);
+  }
+  if (a->wd) {
+    if (dtype == TDN_F16) return launch_block64<true, true, false, 2>(p, (hipStream_t)stream);
+    return launch_block64<true, false, false, 2>(p, (hipStream_t)stream);
   }
   if (dtype == TDN_F16) return launch_block64<true, true, false, 1>(p, (hipStream_t)stream);
   return launch_block64<true, false, false, 1>(p, (hipStream_t)stream);

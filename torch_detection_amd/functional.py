@@ -836,9 +836,10 @@ def _block_fusable(b, C4):
 def _block_head_fusable(b, Cin):
     """The stage's first Bottleneck where it keeps the resolution (layer1.0, resnet.py:130-136: a 1x1 conv + BN
     downsample because inplanes != 4 * planes): conv1 -> conv2 -> conv3 + residual run as one launch whose residual is
-    the downsample branch — computed inside the forward launch (default, TDN_BLOCK_HEAD=2) or by a launch of its own
-    (TDN_BLOCK_HEAD=1; always so in the backward pass: ops.bottleneck_head_fwd / _dgrad).  TDN_BLOCK_HEAD=0 (or
-    TDN_BLOCK_FUSE=0) keeps the per-conv launches."""
+    the downsample branch — computed inside the launch, forward and backward (default, TDN_BLOCK_HEAD=2; 2f: forward
+    only) or by a launch of its own (TDN_BLOCK_HEAD=1): ops.bottleneck_head_fwd / _dgrad.  TDN_BLOCK_HEAD=0 (or
+    TDN_BLOCK_FUSE=0) keeps the per-conv launches.  One box, interleaved: 0 -> 510.7, 1 -> 518.1, 2f -> 520.0,
+    2 -> 523.9 img/s."""
     if b.kind != 'bottleneck' or b.ud is None or b.stride != 1:
         return False
     if os.environ.get('TDN_BLOCK_FUSE', '1') == '0' or os.environ.get('TDN_BLOCK_HEAD', '1') == '0':
@@ -1052,6 +1053,12 @@ def _block_dgrad_fused(b, saved, g, mask_src, outs=None, bits=None):
     return g2, g1, dx
 
 
+def _head_ds_in_launch():
+    """TDN_BLOCK_HEAD=2 (default): the head block's downsample branch is computed inside its launch, forward and
+    backward.  The in-situ parity recorder (DEBUG_BWD) wants the downsample dgrad's result as a tensor: separate launch."""
+    return os.environ.get('TDN_BLOCK_HEAD', '2') not in ('1', '2f') and DEBUG_BWD is None
+
+
 def _block_head_dgrad_fused(b, saved, g, outs=None, bits=None, t_out=None):
     """Input gradients of a head block (_block_head_fusable): the downsample conv's dgrad as a launch of its own, then
     g2, g1 and dx = conv1^T(g1) + t in one launch.  Returns (g2, g1, dx, t)."""
@@ -1059,9 +1066,13 @@ def _block_head_dgrad_fused(b, saved, g, outs=None, bits=None, t_out=None):
     u1, u2, u3 = b.u1, b.u2, b.u3
     if bits is None:
         bits = getattr(h1, '_tdn_bits', None)
-    t = unit_dgrad(b.ud, g, _hw(x), out=t_out)
+    if _head_ds_in_launch():
+        # downsample^T(g) accumulated inside the launch, beside conv3^T(g): g is read once, t never exists in HBM
+        t, down = None, b.ud.w_dgrad
+    else:
+        t, down = unit_dgrad(b.ud, g, _hw(x), out=t_out), None
     g2, g1, dx = ops.bottleneck_head_dgrad(g, u3.w_dgrad, u2.w_dgrad, u1.w_dgrad, (h2, h1), t, outs=outs,
-                                           bits=bits[:2] if bits is not None else None)
+                                           bits=bits[:2] if bits is not None else None, down=down)
     if DEBUG_BWD is not None:
         DEBUG_BWD.append(('dgrad', u3, g, _hw(h2), None, ADD_NONE, h2, g2))
         DEBUG_BWD.append(('dgrad', u2, g2, _hw(h1), None, ADD_NONE, h1, g1))
@@ -1131,9 +1142,11 @@ def _block_bwd_chains(b, saved, g, extra, mask_src, wq, pool, cuts):
     g2 = new_like(h2) if bott else None
     g1 = new_like(h1)
     dx = new_like(x)
-    t = new_like(x) if b.ud is not None else g
     fused = extra is None and _block_fusable(b, x.shape[3])
     head = extra is None and mask_src is None and _block_head_fusable(b, x.shape[3])
+    t = g
+    if b.ud is not None:
+        t = new_like(x) if not (head and _head_ds_in_launch()) else None
     bits_all = getattr(h1, '_tdn_bits', None) if (fused or head) else None
     for i, st in enumerate(pool[:len(cuts) - 1]):
         a, e = cuts[i], cuts[i + 1]
@@ -1149,7 +1162,7 @@ def _block_bwd_chains(b, saved, g, extra, mask_src, wq, pool, cuts):
             if head:
                 _block_head_dgrad_fused(b, (x[a:e], h1[a:e], h2[a:e], None), gi, outs=(g2[a:e], g1[a:e], dx[a:e]),
                                         bits=tuple(t_[a:e] for t_ in bits_all) if bits_all is not None else None,
-                                        t_out=t[a:e])
+                                        t_out=t[a:e] if t is not None else None)
                 continue
             if b.ud is not None:
                 unit_dgrad(b.ud, gi, _hw(x), extra[a:e] if extra is not None else None, ADD_SAME, out=t[a:e])

@@ -386,17 +386,28 @@ def bottleneck_head_fwd(x, w1, w2, w3, affine, res=None, outs=None, bits=None, d
     return o
 
 
-def bottleneck_head_dgrad(g, w3d, w2d, w1d, masks, t, outs=None, bits=None):
-    """Input-gradient chain of that block in one launch: g [N,H,W,4C]; ``t`` [N,H,W,C] = the downsample conv's input
-    gradient; returns (g2, g1, dx) with dx = conv1^T(g1) + t (no mask: x comes from the max pool).  ``masks`` =
-    (h2, h1); ``bits`` = the (b1, b2) planes of the forward call, used instead."""
+def bottleneck_head_dgrad(g, w3d, w2d, w1d, masks, t=None, outs=None, bits=None, down=None):
+    """Input-gradient chain of that block in one launch: g [N,H,W,4C]; returns (g2, g1, dx) with
+    dx = conv1^T(g1) + downsample^T(g) (no mask: x comes from the max pool).  The downsample conv's input gradient is
+    either ``t`` [N,H,W,C] (a launch of its own) or computed inside the launch from ``down`` = its w_dgrad pack
+    [C,1,1,4C].  ``masks`` = (h2, h1); ``bits`` = the (b1, b2) planes of the forward call, used instead."""
     N, H, W, C4 = g.shape
+    C = C4 // 4
+    if (t is None) == (down is None):
+        raise ValueError("bottleneck_head_dgrad: give either t or down")
     if bits is not None and any(b is None for b in bits[:2]):
         raise ValueError("bottleneck_head_dgrad: both bit planes or none")
     bits3 = (bits[0], bits[1], None) if bits is not None else None
     m3 = None if bits is not None else (masks[0], masks[1], None)
     args, o = _bottleneck_args("bottleneck_head_dgrad", g, w3d, w2d, w1d, None, m3, outs, bits3, head='bwd')
-    h = _head_args(args, t, (N, H, W, C4 // 4), g.dtype, "bottleneck_head_dgrad")
+    if t is not None:
+        h = _head_args(args, t, (N, H, W, C), g.dtype, "bottleneck_head_dgrad")
+    else:
+        if down.dtype != g.dtype or tuple(down.shape) != (C, 1, 1, C4) or not down.is_contiguous() or not down.is_cuda:
+            raise ValueError("bottleneck_head_dgrad: downsample w_dgrad must be %s %s contiguous" % (g.dtype, (C, 1, 1, C4)))
+        h = _lib.BottleneckHeadArgs()
+        h.b = args
+        h.wd = down.data_ptr()
     _lib.check(_lib.load().tdn_bottleneck_head_dgrad(ctypes.byref(h), dtype_code(g.dtype), _lib.stream_ptr()),
                "tdn_bottleneck_head_dgrad")
     return o
