@@ -30,6 +30,10 @@ else
   python scripts/halo_ksweep.py 2 200 336 256 > $O/ksweep_p2.log 2>&1
   if [ -f torch_detection_amd/libtdn_trace.so ]; then python scripts/halo_ablate.py > $O/halo_ablate.log 2>&1; fi
   python scripts/wgrad_group_bench.py > $O/wgrad_group_bench.log 2>&1
+  { python scripts/block_bench.py --C 64; python scripts/block_bench.py --C 128 --H 100 --W 168; python scripts/block_bench.py --head; } > $O/block_bench.log 2>&1
+  for v in 0 64 1; do TDN_BLOCK_FUSE=$v python bench.py --no-cpu-baseline --no-secondary --no-kernel-timer > $O/bench_fuse$v.json 2>/dev/null; done
+  TDN_BLOCK_HEAD=0 python bench.py --no-cpu-baseline --no-secondary --no-kernel-timer > $O/bench_head0.json 2>/dev/null
+  TDN_BLOCK_BITS=0 python bench.py --no-cpu-baseline --no-secondary --no-kernel-timer > $O/bench_bits0.json 2>/dev/null
   find $O -name "*_kernel_trace.csv" -size +3M -delete
 fi
 echo done
