@@ -14,6 +14,10 @@ if [ "$PART" = "1" ]; then
   python scripts/trace_timeline.py $O/prof/*/*_kernel_trace.csv > $O/timeline.txt 2>&1
   bash scripts/pmc_bench.sh $O/pmc > $O/pmc_passes.log 2>&1 || exit 1
   python scripts/pmc_summarize.py $O/pmc > $O/pmc_summary.txt || exit 1
+  # the halo kernel with 8 x 16 patches only (every fragment inside one patch row): LDS bank conflicts against the default patches
+  mkdir -p $O/pmc816
+  TDN_HALO_TH=8 TDN_HALO_TW=16 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc816/lds -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-graph > $O/pmc816/lds.log 2>&1 || echo "pmc816 failed"
+  python scripts/pmc_summarize.py $O/pmc816 > $O/pmc816_summary.txt 2>&1
   find $O -name "*_kernel_trace.csv" -size +3M -delete
   find $O -name "*counter_collection.csv" -size +3M -delete
 else

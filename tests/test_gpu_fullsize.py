@@ -20,7 +20,7 @@ from golden_util import det_tensor, fill_state_dict, rel_l2
 pytestmark = pytest.mark.gpu
 
 H, W = 800, 1344
-PLAIN = {"TDN_GEMM_CFG": "0", "TDN_WGRAD9": "0", "TDN_SIDE_STREAM": "0", "TDN_BRANCH": "0", "TDN_IMG_SPLIT_M": "0",
+PLAIN = {"TDN_GEMM_CFG": "0", "TDN_BLOCK_FUSE": "0", "TDN_WGRAD9": "0", "TDN_SIDE_STREAM": "0", "TDN_BRANCH": "0", "TDN_IMG_SPLIT_M": "0",
          "TDN_KG_TILES": "0", "TDN_WGRAD_GROUP": "0", "TDN_SPLITK": "0", "TDN_BWD_SPLIT": "0"}
 
 
