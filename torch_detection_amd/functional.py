@@ -937,8 +937,9 @@ def _splittable(b):
     return all(not (u.gn or u.bnt) and u.groups == 1 for u in b.units())
 
 
-def _blocks_fwd_split(blocks, cur):
-    """Forward of ``blocks`` on batch ``cur`` (N >= 2) as N per-image chains on N streams; returns (out, saved)."""
+def _blocks_fwd_split(blocks, cur, pre=None):
+    """Forward of ``blocks`` on batch ``cur`` (N >= 2) as N per-image chains on N streams; returns (out, saved).
+    ``pre(a, e)``: optional producer of cur[a:e], launched at the head of that image range's chain (the stem)."""
     dev = cur.device
     N = cur.shape[0]
     key = (dev.index, torch._C._cuda_getCurrentRawStream(dev.index))
@@ -994,6 +995,13 @@ def _blocks_fwd_split(blocks, cur):
     # GraphedStep capture streams.wait now refuses it with a RuntimeError (the step then runs eager) — to reproduce the
     # crash itself, capture with a plain torch.cuda.graph (not policed).
     chain_sync = int(os.environ.get('TDN_CHAIN_SYNC', '0'))
+    if pre is not None:
+        for i in range(ways):
+            prev = _lib.set_stream_override(pool[i].cuda_stream)
+            try:
+                pre(cuts[i], cuts[i + 1])
+            finally:
+                _lib.set_stream_override(prev)
     for bi_, (b, (h1, h2, out, res, bits)) in enumerate(zip(blocks, bufs)):
         if chain_sync > 0 and bi_ > 0 and bi_ % chain_sync == 0:
             mode = os.environ.get('TDN_CHAIN_SYNC_MODE', 'cross')
@@ -1199,6 +1207,24 @@ def _stem_fwd(u, xp, hw):
     return s
 
 
+def _stem_pool_split(u, xp, hw):
+    """The one-launch stem + pool per image range, at the head of the per-image forward chains (TDN_STEM_SPLIT, default
+    1): returns (pooled output, indices, pre) with the batch tensors allocated here and ``pre(a, e)`` the launch that
+    fills images a..e — or None where the one-launch stem does not apply."""
+    if (u.gn or u.bnt or u.Cout != 64 or u.scale is None or u.shift is None or DEBUG_CAPTURE is not None or
+            os.environ.get('TDN_STEM_FUSED', '1') == '0' or os.environ.get('TDN_STEM_SPLIT', '1') == '0'):
+        return None
+    H, W = hw
+    N = xp.shape[0]
+    Ho, Wo = ops.conv_out_size(H // 2, 3, 2, 1), ops.conv_out_size(W // 2, 3, 2, 1)
+    y = torch.empty(N, Ho, Wo, u.Cout, dtype=xp.dtype, device=xp.device)
+    idx = torch.empty(N, Ho, Wo, u.Cout, dtype=torch.uint8, device=xp.device)
+
+    def pre(a, e):
+        ops.stem_pool_fwd(xp[a:e], u.w_fwd, hw, u.scale, u.shift, out=(y[a:e], idx[a:e]))
+    return y, idx, pre
+
+
 def _stem_pool_fwd(u, xp, hw):
     """Stem + max pool (resnet.py:254-258): (stem activation or None, pooled output, window indices).  The plain stem —
     64 channels, eval-mode BN folded into the conv — runs as ONE launch that never writes its full-size activation
@@ -1231,11 +1257,12 @@ class SeqNetFunction(torch.autograd.Function):
     def _forward(ctx, net, x, *params):
         st = {}
         s = None
+        stem_pre = None
         if net.stem is not None and isinstance(x, StagedImages):
             if x.dtype != net.dtype:
                 raise RuntimeError('staged images are %s but the net computes in %s' % (x.dtype, net.dtype))
             xp, (H, W) = x.xp, x.hw
-            s, cur, idx = _stem_pool_fwd(net.stem, xp, (H, W))
+            s, cur, idx, stem_pre = SeqNetFunction._stem(net, xp, (H, W))
             st.update(xp=xp, y=cur, idx=idx, img_hw=(H, W))   # the stem's own output is not kept: see maxpool3x3s2_bwd
         elif net.stem is not None:
             if x.dim() != 4 or x.shape[1] != 3:
@@ -1243,7 +1270,7 @@ class SeqNetFunction(torch.autograd.Function):
             img = x if x.dtype == torch.float32 else x.float()
             H, W = img.shape[2], img.shape[3]
             xp = ops.stage_image(img, net.dtype)
-            s, cur, idx = _stem_pool_fwd(net.stem, xp, (H, W))
+            s, cur, idx, stem_pre = SeqNetFunction._stem(net, xp, (H, W))
             st.update(xp=xp, y=cur, idx=idx, img_hw=(H, W))   # the stem's own output is not kept: see maxpool3x3s2_bwd
         else:
             cur = ops.to_nhwc_bf16(x, net.dtype)
@@ -1258,18 +1285,24 @@ class SeqNetFunction(torch.autograd.Function):
             if split_m > 0 and cur.shape[0] >= 2 and m_out <= split_m and \
                     all(_splittable(bb) for bb in net.blocks[bi:]):
                 join_branches(cur.device)
-                cur, svs = _blocks_fwd_split(net.blocks[bi:], cur)
+                cur, svs = _blocks_fwd_split(net.blocks[bi:], cur, pre=stem_pre)
+                stem_pre = None
                 for j, sv in enumerate(svs):
                     saved.append(sv)
                     if bi + j in net.out_blocks:
                         outs.append(sv[3])
                 bi = nb
                 break
+            if stem_pre is not None:       # the chains do not start here after all: the whole batch's stem now
+                stem_pre(0, cur.shape[0])
+                stem_pre = None
             cur, sv = _block_fwd(cur, b)
             saved.append(sv)
             if bi in net.out_blocks:
                 outs.append(cur)
             bi += 1
+        if stem_pre is not None:
+            stem_pre(0, cur.shape[0])
         if not net.blocks:
             outs.append(cur)
         join_branches(cur.device)
@@ -1277,6 +1310,23 @@ class SeqNetFunction(torch.autograd.Function):
         if DEBUG_CAPTURE is not None:      # parity tests look at the stem's activation too; the step itself drops it
             DEBUG_CAPTURE['seq'] = (dict(st, s=s), saved)
         return tuple(_as_nchw(o) for o in outs)
+
+    @staticmethod
+    def _stem(net, xp, hw):
+        """(stem activation | None, pooled output, window indices, pre | None): with ``pre`` the pooled output is still
+        to be produced — per image range, at the head of the per-image chains (_blocks_fwd_split) — which is only done
+        when those chains start at the first block."""
+        N = xp.shape[0]
+        H, W = hw
+        will_split = (_img_split_m() > 0 and N >= 2 and net.blocks and
+                      N * (H // 4) * (W // 4) // (net.blocks[0].stride ** 2) <= _img_split_m() and
+                      all(_splittable(bb) for bb in net.blocks))
+        if will_split:
+            r = _stem_pool_split(net.stem, xp, hw)
+            if r is not None:
+                return None, r[0], r[1], r[2]
+        s, cur, idx = _stem_pool_fwd(net.stem, xp, hw)
+        return s, cur, idx, None
 
     @staticmethod
     def backward(ctx, *douts):

@@ -547,7 +547,7 @@ def stem_conv_fwd(xp, w_stem, hw, scale=None, shift=None, relu=True, out_f32=Fal
     return y
 
 
-def stem_pool_fwd(xp, w_stem, hw, scale, shift):
+def stem_pool_fwd(xp, w_stem, hw, scale, shift, out=None):
     """conv7x7/s2 + folded BN + ReLU + MaxPool2d(3, 2, 1) in one launch (``tdn_stem_pool_fwd``): returns the pooled
     output and the window indices, bit-identical to ``maxpool3x3s2_fwd(stem_conv_fwd(...))``; 64 output channels."""
     H, W = hw
@@ -563,8 +563,12 @@ def stem_pool_fwd(xp, w_stem, hw, scale, shift):
         if t is None or t.dtype != torch.float32 or t.numel() != Cout or not t.is_contiguous() or t.device != xp.device:
             raise ValueError("stem_pool_fwd: %s must be a contiguous float32 [%d] tensor on the image's device" % (nm, Cout))
     Ho, Wo = conv_out_size(H // 2, 3, 2, 1), conv_out_size(W // 2, 3, 2, 1)
-    y = torch.empty(N, Ho, Wo, Cout, dtype=xp.dtype, device=xp.device)
-    idx = torch.empty(N, Ho, Wo, Cout, dtype=torch.uint8, device=xp.device)
+    if out is not None:     # caller-provided buffers (one image range of batch tensors)
+        y = _out_buffer(out[0], (N, Ho, Wo, Cout), xp.dtype, "stem_pool_fwd")
+        idx = _out_buffer(out[1], (N, Ho, Wo, Cout), torch.uint8, "stem_pool_fwd")
+    else:
+        y = torch.empty(N, Ho, Wo, Cout, dtype=xp.dtype, device=xp.device)
+        idx = torch.empty(N, Ho, Wo, Cout, dtype=torch.uint8, device=xp.device)
     _lib.check(_lib.load().tdn_stem_pool_fwd(_ptr(xp), _ptr(w_stem), _ptr(scale), _ptr(shift), _ptr(y), _ptr(idx), N, H,
                                              W, Cout, dtype_code(xp.dtype), _lib.stream_ptr()), "tdn_stem_pool_fwd")
     return y, idx
