@@ -145,3 +145,51 @@ def test_reducer_bucket_layout():
             red.mark_ready(0)
             red.mark_ready(0)
     assert dp.shard_for_rank(16, 3, 8) == slice(6, 8)
+
+
+def _worker_modes(rank, world, port, out_dir):
+    """The three launch points of a complete bucket's all-reduce (TDN_DP_LAUNCH) reduce the same values; 'late' holds a
+    complete bucket back until the backward schedule reports its second-to-last stage, 'finish' until finish()."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch_detection_amd import dp
+    numels = [300000, 200000, 100000, 50000]
+    vals = [det_tensor((n,), 40 + i + 10 * rank, -1, 1) for i, n in enumerate(numels)]
+    res = {}
+    for mode in ("ready", "late", "finish", "2"):
+        os.environ["TDN_DP_LAUNCH"] = mode
+        red = dp.GradReducer(numels, "cpu", bucket_bytes=1 << 20)
+        assert len(red.buckets) >= 2 and red.bucket_of[0] == 0 and red.bucket_of[1] != 0
+        red.views[0].copy_(vals[0])
+        red.mark_ready(0)                       # bucket 0 is complete now
+        assert (0 in red._launched) == (mode == "ready"), mode
+        red.on_flush_point(1, 4)
+        assert (0 in red._launched) == (mode == "ready"), mode
+        red.on_flush_point(2, 4)
+        assert (0 in red._launched) == (mode in ("ready", "2")), mode
+        red.on_flush_point(3, 4)                # the pass enters its last stage
+        assert (0 in red._launched) == (mode != "finish"), mode
+        for i in range(1, len(numels)):
+            red.views[i].copy_(vals[i])
+            red.mark_ready(i)
+        red.finish()
+        res[mode] = [v.clone() for v in red.views]
+    os.environ.pop("TDN_DP_LAUNCH")
+    for mode in ("late", "finish", "2"):
+        assert all(torch.equal(a, b) for a, b in zip(res["ready"], res[mode])), mode
+    torch.save(res["late"], os.path.join(out_dir, "modes%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucket_launch_points(tmp_path):
+    world = 2
+    mp.spawn(_worker_modes, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(os.path.join(str(tmp_path), "modes0.pt"), weights_only=True)
+    b = torch.load(os.path.join(str(tmp_path), "modes1.pt"), weights_only=True)
+    numels = [300000, 200000, 100000, 50000]
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y)
+        want = (det_tensor((numels[i],), 40 + i, -1, 1) + det_tensor((numels[i],), 50 + i, -1, 1)) / 2
+        assert torch.allclose(x, want, rtol=0, atol=1e-7)

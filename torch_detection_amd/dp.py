@@ -74,11 +74,38 @@ class GradReducer(object):
         # collective the 8-GPU step captures.
         self._avg_in_collective = bool(self.enabled and self.average and self.use_streams and
                                        self.comm_dtype is None and dist.get_backend(group) == 'nccl')
+        # When a complete bucket's all-reduce is launched (TDN_DP_LAUNCH):
+        #   ready   at its last gradient — the most overlap on paper; but inside the captured step the collective nodes
+        #           then sit in the middle of the backward pass and the runtime's 4-lane graph executor
+        #           serialises weight-gradient groups and dgrad chains behind them: 437 img/s on ONE rank, where the
+        #           collective itself is a copy, against 527 without a reducer
+        #   late    (default) when the backward pass enters its last stage (functional.FLUSH_HOOKS: all but one stage's
+        #           weight-gradient groups launched): three of R50-FPN's four 32 MiB buckets start there and overlap
+        #           layer1 and the tail of the pass, the last one follows from finish(): 509 img/s on one rank
+        #   finish  all from finish() (no overlap): 505-510;   <n>: at the n-th stage (1, 2: as bad as ready)
+        import os
+        self.launch_mode = os.environ.get('TDN_DP_LAUNCH', 'late')
+        self.defer = self.launch_mode != 'ready'
         self._pending = None
         self._works = []
         self.reset()
 
+    def on_flush_point(self, n, nstages):
+        """functional.FLUSH_HOOKS: the backward pass has launched the weight-gradient groups of n of its nstages stages."""
+        if not self.defer or self.launch_mode == 'finish':
+            return
+        at = int(self.launch_mode) if self.launch_mode.isdigit() else max(1, nstages - 1)
+        if n >= at:
+            self.flush_deferred()
+
+    def flush_deferred(self):
+        """Launch the all-reduce of every complete bucket whose launch was put off (``defer``)."""
+        todo, self._deferred = self._deferred, []
+        for b in todo:
+            self._launch(b)
+
     def reset(self):
+        self._deferred = []
         self._pending = [b[2] for b in self.buckets]
         self._works = []
         self._launched = []                            # buckets reduced this step, in launch order
@@ -105,7 +132,10 @@ class GradReducer(object):
         if self.use_streams and stream is not None:
             self._producers[b][stream.cuda_stream] = stream
         if self._pending[b] == 0:
-            self._launch(b)
+            if self.defer:
+                self._deferred.append(b)
+            else:
+                self._launch(b)
         elif self._pending[b] < 0:
             raise RuntimeError('GradReducer: bucket %d got more gradients than it has slots in one step '
                                '(call reset()/finish())' % b)
@@ -152,6 +182,7 @@ class GradReducer(object):
                     self.flat[o:o + n].zero_()
             for b in missing:
                 self._launch(b)
+        self.flush_deferred()
         for w in self._works:
             w.wait()
         if self.use_streams and self.enabled:
@@ -226,6 +257,19 @@ def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True, dty
             for b_, ss_ in _pb:
                 _red.mark_ready_n(b_, len(ss_), stream, ss_)
         u.on_grads = _cb
+    # the backward schedule tells the reducer when a stage's weight-gradient groups have been launched (held weakly:
+    # a dropped reducer drops out of the hook list)
+    import weakref
+    from . import functional
+    ref = weakref.ref(red)
+
+    def _hook(n, nstages, _ref=ref):
+        r = _ref()
+        if r is not None:
+            r.on_flush_point(n, nstages)
+    functional.FLUSH_HOOKS[:] = [h for h in functional.FLUSH_HOOKS if getattr(h, '_ref', lambda: None)() is not None]
+    _hook._ref = ref
+    functional.FLUSH_HOOKS.append(_hook)
     return red
 
 

@@ -1239,6 +1239,12 @@ def _stem_pool_fwd(u, xp, hw):
     return s, y, idx
 
 
+# Called by SeqNetFunction._backward behind every weight-gradient group launch of a stage, with the number of stages
+# whose groups have been launched so far in this pass (1: the last stage's, ...) and the number of stages:
+# dp.GradReducer hangs the launch of its deferred bucket all-reduces on it.
+FLUSH_HOOKS = []
+
+
 class SeqNetFunction(torch.autograd.Function):
     """ResNet.forward (resnet.py:253-268) — or a single residual block — as one autograd node."""
 
@@ -1346,6 +1352,8 @@ class SeqNetFunction(torch.autograd.Function):
         wq = WgradQueue(ctx.dev)
         flush_every = int(os.environ.get('TDN_WGRAD_FLUSH', '0'))
         since_flush = 0
+        nflush = 0
+        nstages = sum(1 for b_ in net.blocks if b_.ud is not None)
         # Per-image dgrad chains (default; TDN_BWD_SPLIT=0 turns them off): like the forward's, the dgrad launches of
         # each image range go to that range's stream, block by block in alternation — the stretches of the backward
         # pass where a chain of small dgrad kernels had the GPU to itself become two half-size chains side by side
@@ -1408,6 +1416,9 @@ class SeqNetFunction(torch.autograd.Function):
                     join_chains()
                 wq.flush()
                 since_flush = 0
+                nflush += 1
+                for hook in FLUSH_HOOKS:
+                    hook(nflush, nstages)
         if chains is not None and started:
             join_chains()
         dx_in = None
