@@ -320,3 +320,51 @@ def test_head_block_forward_and_dgrad(ops, generic_tiles, N, H, W, dtype, with_b
         ne = a.view(torch.int16) != b.view(torch.int16)
         assert not bool(ne.any()), "in-launch downsample, %s: %d of %d elements differ, first %s" % (
             name, int(ne.sum()), a.numel(), ne.nonzero()[:4].tolist())
+
+
+# ---------------------------------------------------------------------------------------------------
+# C = 128 with 10 x 16 tiles (bottleneck128t_kernel; chosen by the library where it saves a round of workgroups)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W", SHAPES + [(1, 100, 168), (2, 100, 168), (1, 31, 50)])
+@pytest.mark.parametrize("mode", ["masks", "nomask3", "bits"])
+def test_block128_tall_tiles(ops, generic_tiles, monkeypatch, N, H, W, dtype, mode):
+    """Forward and input-gradient chain with the 10-row tile forced, bit for bit against the per-conv launches; the bit
+    planes it writes are exactly the signs of the stored tensors."""
+    C, C4 = 128, 512
+    monkeypatch.setenv("TDN_BLOCK128_TH", "10")
+    x, w1, w2, w3, aff = _case(N, H, W, C, dtype, 77 * H + W)
+    dev = torch.device("cuda")
+    xg, w1g, w2g, w3g = (t.contiguous().to(dev) for t in (x, w1, w2, w3))
+    affg = [a.to(dev) for a in aff]
+    bits = None
+    if mode == "bits":
+        bits = ops.bottleneck_bit_planes(N, H, W, C, dev)
+        for b in bits:
+            b.fill_(0x5A5A5A5A)
+    h1, h2, out = ops.bottleneck_fwd(xg, w1g, w2g, w3g, affg, bits=bits)
+    r1 = ops.conv2d_fwd(xg, w1g, 1, 1, 0, affg[0], affg[1], relu=True)
+    r2 = ops.conv2d_fwd(r1, w2g, 3, 1, 1, affg[2], affg[3], relu=True)
+    r3 = ops.conv2d_fwd(r2, w3g, 1, 1, 0, affg[4], affg[5], xg, ops.ADD_SAME, True)
+    torch.cuda.synchronize()
+    for name, a, b in (("h1", h1, r1), ("h2", h2, r2), ("out", out, r3)):
+        ne = a.view(torch.int16) != b.view(torch.int16)
+        assert not bool(ne.any()), "%s: %d of %d elements differ, first %s" % (name, int(ne.sum()), a.numel(), ne.nonzero()[:4].tolist())
+    if bits is not None:
+        for name, b, ref, ch in (("h1", bits[0], h1, C), ("h2", bits[1], h2, C), ("x", bits[2], xg, C4)):
+            assert torch.equal(_unpack_bits(b, ch), (ref.float().cpu() > 0)), name
+    w1d, w2d, w3d = (w.permute(3, 1, 2, 0).contiguous() for w in (w1g, w2g, w3g))
+    g = torch.where(out > 0, (det_tensor((N, H, W, C4), 313) * 0.1).to(dtype).to(dev), torch.zeros((), device=dev, dtype=dtype))
+    g = g.contiguous()
+    m3 = None if mode == "nomask3" else xg
+    if bits is not None:
+        g2, g1, dx = ops.bottleneck_dgrad(g, w3d, w2d, w1d, None, bits=bits)
+    else:
+        g2, g1, dx = ops.bottleneck_dgrad(g, w3d, w2d, w1d, (h2, h1, m3))
+    q2 = ops.conv2d_dgrad(g, w3d, (H, W), 1, 1, 0, mask_src=h2)
+    q1 = ops.conv2d_dgrad(q2, w2d, (H, W), 3, 1, 1, mask_src=h1)
+    qx = ops.conv2d_dgrad(q1, w1d, (H, W), 1, 1, 0, g, ops.ADD_SAME, m3)
+    torch.cuda.synchronize()
+    for name, a, b in (("g2", g2, q2), ("g1", g1, q1), ("dx", dx, qx)):
+        ne = a.view(torch.int16) != b.view(torch.int16)
+        assert not bool(ne.any()), "%s: %d of %d elements differ, first %s" % (name, int(ne.sum()), a.numel(), ne.nonzero()[:4].tolist())

@@ -1427,6 +1427,475 @@ __global__ __launch_bounds__(512, 1) void bottleneck128_kernel(const BlockParams
 }
 
 // ---------------------------------------------------------------------------------------------
+// C = 128 with 10 x 16 tiles ("tall").  Why: layer2's 100 x 168 map makes 13 x 11 = 143 tiles of 8 x 16 per image; the
+// two images' launches of a step run side by side, 286 workgroups on 256 CUs — two rounds for 1.12 rounds of work
+// (stand-alone, both images in one launch: 57.6 us; 242 tiles of the same kernel: 35.2 us).  10 x 16 tiles are
+// 10 x 11 = 110 per image, 220 for the pair: one round of 1.25x longer workgroups, and H = 100 has no ragged band.
+// Same three phases, 8 waves = 2 pixel halves (7 + 7 patch fragments, 5 + 5 tile rows) x 4 channel quarters:
+//   [0, 57344)          H1[224 rows][256 B]   (later H2[160 rows][256 B])
+//   [57344, 163840)     phase 1: four K-step slots of 22528 B (X 224 rows x 64 B + W1 128 rows x 64 B); then six 16 KB
+//                       unit slots — five over the first 80 KB, the sixth behind the K-step slots (free from the
+//                       start: unit 0 is issued there at kernel start), unit u in slot (u + 5) % 6
+// Units: u = 0..17 conv2 as in the 8 x 16 kernel; u = 18..25 conv3 in FOUR passes of 128 output channels (pass q: units
+// 18 + 2q, 19 + 2q = the two K halves), 8 channels per lane like the other phases — 40 accumulator registers per pass
+// instead of 64, which is what makes room for the fifth tile row.  Five units stay in flight (counted vmcnt).
+// ---------------------------------------------------------------------------------------------
+template <bool BWD, bool F16, bool MB = false>
+__global__ __launch_bounds__(512, 1) void bottleneck128t_kernel(const BlockParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int C = 128, C4 = 512, TH = 10, TW = 16, HWD = TW + 2, PH = (TH + 2) * HWD /* 216 */, PHP = 224;
+  constexpr int NF1 = PHP / 32;                // 7 patch fragments per wave
+  constexpr int NF2 = TH / 2;                  // 5 tile rows per wave
+  constexpr int RB = 256;                      // H1 / H2 row bytes
+  constexpr int WRB = 128;                     // weight unit row bytes
+  constexpr int RING = PHP * RB, UB = 16384;   // 57344
+  constexpr int XB32 = PHP * 64, P1SLOT = XB32 + 8192;   // 14336, 22528
+  constexpr int KS1 = C4 / 32;                 // 16 K-steps of 32 channels
+  constexpr int NOP = BWD ? 2 * NF2 : NF2;     // unconditional per-pixel operand loads of a phase 3 pass (addend [+ mask])
+  static_assert(RING + 4 * P1SLOT + UB == 163840, "LDS map");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int bid = blockIdx.x;
+  const int tile = (bid & 7) * (p.nwg_pad >> 3) + (bid >> 3);
+  if (tile >= p.ntiles) return;
+  const int H = p.H, W = p.W;
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int img = tile / tpi;
+  const int trem = tile - img * tpi;
+  const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int64_t img_pix0 = (int64_t)img * H * W;
+
+  auto swz_w8 = [](int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); };
+  auto f256 = [](int R) { return ((R >> 1) & 7) << 1; };
+
+  // ---- weight units ----
+  const int lrow8 = lane >> 3, lchunk8 = lane & 7;
+  auto unit_off = [](int u) { return (u + 5) % 6 < 5 ? RING + ((u + 5) % 6) * UB : RING + 4 * P1SLOT; };
+  auto load_unit = [&](int u) {
+    char* dst = smem + unit_off(u);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int g8 = it * 8 + wave;
+      const int r = g8 * 8 + lrow8;                  // row of the unit
+      const char* src;
+      if (u < 18) {
+        const int h = u / 9, t = u - h * 9;
+        src = (const char*)p.w2 + ((int64_t)r * (9 * C) + t * C + h * 64) * 2 + ((lchunk8 ^ swz_w8(r)) * 16);
+      } else {
+        const int v = u - 18, q = v >> 1, h = v & 1;
+        src = (const char*)p.w3 + ((int64_t)(q * 128 + r) * C + h * 64) * 2 + ((lchunk8 ^ swz_w8(r)) * 16);
+      }
+      glds16_async(src, dst + g8 * 8 * WRB);
+    }
+  };
+  load_unit(0);
+
+  // ---- phase 1 loader: per K-step 14 X pieces (16 rows x 64 B) + 8 W1 pieces over 8 waves: every wave issues three
+  // LDS-DMA instructions (waves 6, 7 have no second X piece: a dummy copy of the zero page into the idle H1 region
+  // keeps the per-wave vmcnt arithmetic uniform) ----
+  const int lrow16 = lane >> 2, lchunk4 = lane & 3;
+  const char* zero = (const char*)g_zero_page + lchunk4 * 16;
+  const char* xsrc[2];
+  unsigned xok = 0;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int R = (it * 8 + wave) * 16 + lrow16;
+    const int hy = R / HWD, hx = R - hy * HWD;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
+    const int swz = (4 - ((R >> 2) & 3)) & 3;
+    xsrc[it] = (const char*)p.a + ((img_pix0 + (int64_t)y * W + x) * C4 + ((lchunk4 ^ swz) * 8)) * 2;
+    xok |= ok ? (1u << it) : 0u;
+  }
+  const char* w1src;
+  {
+    const int n = wave * 16 + lrow16;
+    w1src = (const char*)p.w1 + ((int64_t)n * C4) * 2 + ((lchunk4 ^ ((4 - ((n >> 3) & 3)) & 3)) * 16);
+  }
+  auto load_step = [&](int kc) {
+    char* sX = smem + RING + (kc & 3) * P1SLOT;
+    glds16_async(xok & 1u ? xsrc[0] + kc * 64 : zero, sX + wave * 1024);
+    if (wave < 6) glds16_async(xok & 2u ? xsrc[1] + kc * 64 : zero, sX + (8 + wave) * 1024);
+    else glds16_async(zero, smem + wave * 1024);            // dummy, into the idle H1 region
+    glds16_async(w1src + kc * 64, sX + XB32 + wave * 1024);
+  };
+
+  const int f_rd_w = ((fr & 3) >> 1) | ((fr >> 2) << 1);
+  const int f_rd32 = (4 - (fr >> 2)) & 3;
+  const int wrow8 = wn * 32 + (fr >> 2) * 8 + (fr & 3);
+  const int pi = fr < 4 ? 2 * fr : (fr >= 12 ? 2 * (fr - 8) : 2 * (fr - 4) + 1);
+  const int cb8 = wn * 32 + fq * 8;
+
+  auto sel4 = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3) { return fq == 0 ? a0 : (fq == 1 ? a1 : (fq == 2 ? a2 : a3)); };
+  auto load_affine = [&](const float* scp, const float* shp, int ch, f32x4_t& sc, f32x4_t& sh) {
+    sc = (!BWD && scp) ? *(const f32x4_t*)(scp + ch) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+    sh = (!BWD && shp) ? *(const f32x4_t*)(shp + ch) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
+  f32x4_t sc1v[2], sh1v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) load_affine(p.sc1, p.sh1, cb8 + 4 * i, sc1v[i], sh1v[i]);
+  bf16x8_t mk1[MB ? 1 : NF1];
+  unsigned mw1[MB ? NF1 : 1];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int j = 0; j < NF1; ++j) {
+      const int R = wm * (NF1 * 16) + j * 16 + fr;
+      const int hy = R / HWD, hx = R - hy * HWD;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
+      const int64_t pix = img_pix0 + (int64_t)y * W + x;
+      if constexpr (MB) mw1[j] = *(ok ? p.b2 + pix * (C / 32) + wn : (const unsigned*)g_blk_zero);
+      else mk1[j] = *(const bf16x8_t*)((ok && p.m1) ? p.m1 + pix * C + cb8 : (const bf16_t*)g_blk_zero);
+    }
+  }
+
+  // ================= phase 1 =================
+  f32x4_t acc1[2][NF1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NF1; ++j) acc1[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  load_step(0);
+  load_step(1);
+  load_step(2);
+#pragma unroll
+  for (int kc = 0; kc < KS1; ++kc) {
+    // younger than K-step kc at this point: two K-steps (3 LDS-DMA each), or the units that take their place at the tail
+    if (kc <= KS1 - 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (kc == KS1 - 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kc + 3 < KS1) load_step(kc + 3);
+    else load_unit(kc + 3 - KS1 + 1);            // kc = 13, 14, 15 -> units 1, 2, 3: unit slots 0, 1, 2 lie inside the
+                                                 // K-step slots released by then (0; 0 + 1; 1 + 2)
+    const char* sX = smem + RING + (kc & 3) * P1SLOT + (wm * (NF1 * 16) + fr) * 64 + ((fq ^ f_rd32) * 16);
+    const char* sW = smem + RING + (kc & 3) * P1SLOT + XB32 + wrow8 * 64 + ((fq ^ f_rd32) * 16);
+    bf16x8_t wf[2], xf[NF1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wf[i] = lds_read_b128(sW + i * 4 * 64);
+#pragma unroll
+    for (int j = 0; j < NF1; ++j) xf[j] = lds_read_b128(sX + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NF1; ++j) acc1[i][j] = mfma16<F16>(wf[i], xf[j], acc1[i][j]);
+  }
+  lds_barrier();   // b0: the K-step slots are free
+  // compiler-visible loads / stores of this stretch go in front of units 4 and 5 (see the 8 x 16 kernel)
+  bf16x8_t mk2[MB ? 1 : NF2];
+  unsigned mw2[MB ? NF2 : 1];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int j = 0; j < NF2; ++j) {
+      const int y = y0 + wm * NF2 + j, x = x0 + pi;
+      const bool ok = (y < H) && (x < W);
+      const int64_t pix = img_pix0 + (int64_t)y * W + x;
+      if constexpr (MB) mw2[j] = *(ok ? p.b1 + pix * (C / 32) + wn : (const unsigned*)g_blk_zero);
+      else mk2[j] = *(const bf16x8_t*)((p.m2 && ok) ? p.m2 + pix * C + cb8 : (const bf16_t*)g_blk_zero);
+    }
+  }
+
+  bf16x8_t o1v[NF1];
+  unsigned b1w[8];
+  unsigned st1 = 0;
+  b1w[7] = 0u;
+#pragma unroll
+  for (int j = 0; j < NF1; ++j) {
+    const int R = wm * (NF1 * 16) + j * 16 + fr;
+    const int hy = R / HWD, hx = R - hy * HWD;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = (R < PH) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
+    f32x4_t v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] = acc1[i][j] * sc1v[i] + sh1v[i];
+    if constexpr (BWD) {
+      if (MB || p.m1) {
+        const unsigned m = MB ? (mw1[MB ? j : 0] >> (8 * fq)) : pos_bits8<F16>(mk1[MB ? 0 : j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[0][e] = ((m >> e) & 1u) ? v[0][e] : 0.f;
+          v[1][e] = ((m >> (4 + e)) & 1u) ? v[1][e] : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
+    }
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = f32_to_elem<F16>(ok ? v[0][e] : 0.f);
+      o[4 + e] = f32_to_elem<F16>(ok ? v[1][e] : 0.f);
+    }
+    *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + R * RB + (((wn * 4 + fq) ^ f256(R)) * 16)) = o;
+    o1v[j] = o;
+    st1 |= (ok && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW) ? (1u << j) : 0u;
+    b1w[j] = 0u;
+    if constexpr (!BWD) {
+      if (p.b1) b1w[j] = gather_word4(pos_bits8<F16>(o), fq);   // wave-uniform branch: every lane shuffles
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NF1; ++j) {   // h1 / g2 to HBM
+    if ((st1 >> j) & 1u) {
+      const int R = wm * (NF1 * 16) + j * 16 + fr;
+      const int hy = R / HWD, hx = R - hy * HWD;
+      const int64_t pix = img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx);
+      *(bf16x8_t*)(p.o1 + pix * C + cb8) = o1v[j];
+    }
+  }
+  if constexpr (!BWD) {
+    if (p.b1) {   // h1 > 0 words: lane fq stores fragment fq's (then fragment 4 + fq's) word of its pixel column
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int j = r * 4 + fq;
+        const unsigned w = r == 0 ? sel4(b1w[0], b1w[1], b1w[2], b1w[3]) : sel4(b1w[4], b1w[5], b1w[6], 0u);
+        const int R = wm * (NF1 * 16) + j * 16 + fr;
+        const int hy = R / HWD, hx = R - hy * HWD;
+        const bool st = j < NF1 && ((st1 >> j) & 1u);
+        const int64_t pix = img_pix0 + (int64_t)(y0 - 1 + hy) * W + (x0 - 1 + hx);
+        *(st ? p.b1 + pix * (C / 32) + wn : (unsigned*)g_blk_sink) = w;
+      }
+    }
+  }
+  load_unit(4);
+  load_unit(5);
+
+  // ================= phase 2: 18 units =================
+  f32x4_t acc2[2][NF2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NF2; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // per output pixel (dealt pixel pi of tile row wm * 5 + j) only the pixel index is kept (-1: outside the image)
+  int pixj[NF2];
+#pragma unroll
+  for (int j = 0; j < NF2; ++j) {
+    const int y = y0 + wm * NF2 + j, x = x0 + pi;
+    pixj[j] = ((y < H) && (x < W)) ? (int)(img_pix0 + (int64_t)y * W + x) : -1;
+  }
+  // phase 3 operands of pass q: this lane's 8 channels q * 128 + cb8 .. + 7 of its five pixels
+  bf16x8_t ad[NF2], mk3[MB ? 1 : NF2];
+  unsigned mw3[MB ? NF2 : 1];
+  auto load_ops3 = [&](int q) {
+#pragma unroll
+    for (int j = 0; j < NF2; ++j)
+      ad[j] = *(const bf16x8_t*)(pixj[j] >= 0 ? p.a + (int64_t)pixj[j] * C4 + q * 128 + cb8 : (const bf16_t*)g_blk_zero);
+    if constexpr (BWD && !MB) {
+#pragma unroll
+      for (int j = 0; j < NF2; ++j)
+        mk3[j] = *(const bf16x8_t*)((pixj[j] >= 0 && p.m3) ? p.m3 + (int64_t)pixj[j] * C4 + q * 128 + cb8 : (const bf16_t*)g_blk_zero);
+    }
+    if constexpr (MB) {
+#pragma unroll
+      for (int j = 0; j < NF2; ++j)
+        mw3[j] = *(pixj[j] >= 0 ? p.b3 + (int64_t)pixj[j] * (C4 / 32) + q * 4 + wn : (const unsigned*)g_blk_zero);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < 18; ++u) {
+    // unit u landed for every wave; the slot of unit u - 1 is free.  In flight behind it: units u + 1 .. u + 4
+    // (u = 0: .. u + 5), two LDS-DMA instructions each; u = 10 .. 14: also the NOP operand loads issued at u == 9
+    if (u == 0) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // + H1 complete
+    else if (u >= 10 && u <= 14) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(8 + NOP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (u >= 1) load_unit(u + 5);
+    if (u == 9) load_ops3(0);
+    const int h = u / 9, t = u - h * 9;
+    const int ky = t / 3, kx = t - ky * 3;
+    const int oy = BWD ? 2 - ky : ky, ox = BWD ? 2 - kx : kx;
+    const char* sW = smem + unit_off(u) + wrow8 * WRB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t wf[2], xf[NF2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[i] = lds_read_b128(sW + i * 4 * WRB + (((kk * 4 + fq) ^ f_rd_w) * 16));
+#pragma unroll
+      for (int j = 0; j < NF2; ++j) {
+        const int R = (wm * NF2 + j + oy) * HWD + pi + ox;
+        xf[j] = lds_read_b128(smem + R * RB + (((h * 8 + kk * 4 + fq) ^ f256(R)) * 16));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NF2; ++j) acc2[i][j] = mfma16<F16>(wf[i], xf[j], acc2[i][j]);
+    }
+  }
+  lds_barrier();   // b4: H1 is dead; the slot of unit 17 is free
+  f32x4_t sc3v[2], sh3v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) load_affine(p.sc3, p.sh3, cb8 + 4 * i, sc3v[i], sh3v[i]);
+  unsigned b2w[8];
+  {
+    f32x4_t sc2v[2], sh2v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) load_affine(p.sc2, p.sh2, cb8 + 4 * i, sc2v[i], sh2v[i]);
+    asm volatile("" ::: "memory");   // the loads above stay in front of the unit below
+    load_unit(23);
+#pragma unroll
+    for (int j = 0; j < NF2; ++j) {
+      f32x4_t v[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = acc2[i][j] * sc2v[i] + sh2v[i];
+      if constexpr (BWD) {
+        if (MB || p.m2) {
+          const unsigned m = MB ? (mw2[MB ? j : 0] >> (8 * fq)) : pos_bits8<F16>(mk2[MB ? 0 : j]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[0][e] = ((m >> e) & 1u) ? v[0][e] : 0.f;
+            v[1][e] = ((m >> (4 + e)) & 1u) ? v[1][e] : 0.f;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
+      }
+      bf16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = f32_to_elem<F16>(v[0][e]);
+        o[4 + e] = f32_to_elem<F16>(v[1][e]);
+      }
+      const int pr = (wm * NF2 + j) * TW + pi;
+      *(TDN_LDS bf16x8_t*)(TDN_LDS char*)(smem + pr * RB + (((wn * 4 + fq) ^ f256(pr)) * 16)) = o;
+      *(bf16x8_t*)(pixj[j] >= 0 ? p.o2 + (int64_t)pixj[j] * C + cb8 : (bf16_t*)g_blk_sink) = o;   // h2 / g1 to HBM
+      b2w[j] = 0u;
+      if constexpr (!BWD) {
+        if (p.b2) b2w[j] = gather_word4(pos_bits8<F16>(o), fq);
+      }
+    }
+    if constexpr (!BWD) {
+      if (p.b2) {   // h2 > 0 words: lane fq stores tile row wm * 5 + fq's word of its pixel column, lane 0's group row 4's
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const unsigned w = r == 0 ? sel4(b2w[0], b2w[1], b2w[2], b2w[3]) : b2w[4];
+          const int pj = r == 0 ? (int)sel4((unsigned)pixj[0], (unsigned)pixj[1], (unsigned)pixj[2], (unsigned)pixj[3]) : pixj[4];
+          const bool st = pj >= 0 && (r == 0 || fq == 0);
+          *(st ? p.b2 + (int64_t)pj * (C / 32) + wn : (unsigned*)g_blk_sink) = w;
+        }
+      }
+    }
+  }
+  // b5: H2 complete; conv3 units 18, 19 landed.  Younger than unit 19 in this wave's queue: units 20 .. 23 (8 LDS-DMA)
+  // and the 5 unconditional h2 / g1 stores above
+  asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // ================= phase 3: four passes of 128 channels =================
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    __builtin_amdgcn_sched_barrier(0);
+    // pass q > 0: its units 18 + 2q, 19 + 2q have landed for every wave.  Younger than unit 19 + 2q in this wave's
+    // queue (all unconditional): see the table in the comment of each case
+    if (q == 1)        // unit 22, 23 (4), h2 stores (5), units 24, 25 (4), pass 1 operands (NOP), pass 0 stores (5)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(18 + NOP) : "memory");
+    else if (q == 2)   // h2 stores (5), units 24, 25 (4), operands of passes 1, 2 (2 NOP), stores of passes 0, 1 (10)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(19 + 2 * NOP) : "memory");
+    else if (q == 3)   // operands of passes 1, 2, 3 (3 NOP), stores of passes 0, 1, 2 (15)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(15 + 3 * NOP) : "memory");
+    f32x4_t acc3[2][NF2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NF2; ++j) acc3[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const char* sW = smem + unit_off(18 + 2 * q + h) + wrow8 * WRB;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8_t wf[2], xf[NF2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[i] = lds_read_b128(sW + i * 4 * WRB + (((kk * 4 + fq) ^ f_rd_w) * 16));
+#pragma unroll
+        for (int j = 0; j < NF2; ++j) {
+          const int pr = (wm * NF2 + j) * TW + pi;
+          xf[j] = lds_read_b128(smem + pr * RB + (((h * 8 + kk * 4 + fq) ^ f256(pr)) * 16));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NF2; ++j) acc3[i][j] = mfma16<F16>(wf[i], xf[j], acc3[i][j]);
+      }
+    }
+    if (q == 0) {
+      lds_barrier();     // b6: every wave is done with units 18, 19
+      load_unit(24);     // into their slots
+      load_unit(25);
+    }
+    // this pass's epilogue values, then (opaque uses / definition: see bottleneck64_kernel) the next pass's operands
+    bf16x8_t ov[NF2];
+    unsigned b3w[8];
+#pragma unroll
+    for (int j = 0; j < NF2; ++j) {
+      f32x4_t v[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = acc3[i][j] * sc3v[i] + sh3v[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[0][e] += elem_to_f32<F16>(ad[j][e]);
+        v[1][e] += elem_to_f32<F16>(ad[j][4 + e]);
+      }
+      if constexpr (BWD) {
+        unsigned m;
+        if constexpr (MB) m = mw3[MB ? j : 0] >> (8 * fq);
+        else m = p.m3 ? pos_bits8<F16>(mk3[MB ? 0 : j]) : 0xffu;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[0][e] = ((m >> e) & 1u) ? v[0][e] : 0.f;
+          v[1][e] = ((m >> (4 + e)) & 1u) ? v[1][e] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ov[j][e] = f32_to_elem<F16>(v[0][e]);
+        ov[j][4 + e] = f32_to_elem<F16>(v[1][e]);
+      }
+      b3w[j] = 0u;
+      if constexpr (!BWD) {
+        if (p.b3) b3w[j] = gather_word4(pos_bits8<F16>(ad[j]), fq);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NF2; ++j) asm volatile("" ::"v"(ov[j]));
+    __builtin_amdgcn_sched_barrier(0);
+    if (q < 3) {
+      int qn = q + 1;
+      asm volatile("" : "+s"(qn));
+      load_ops3(qn);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) load_affine(p.sc3, p.sh3, qn * 128 + cb8 + 4 * i, sc3v[i], sh3v[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < NF2; ++j)
+      *(bf16x8_t*)(pixj[j] >= 0 ? p.o3 + (int64_t)pixj[j] * C4 + q * 128 + cb8 : (bf16_t*)g_blk_sink) = ov[j];
+    if constexpr (!BWD) {
+      if (p.b3) {   // x > 0 words of this pass's 128 channels: word q * 4 + wn of the pixel
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const unsigned w = r == 0 ? sel4(b3w[0], b3w[1], b3w[2], b3w[3]) : b3w[4];
+          const int pj = r == 0 ? (int)sel4((unsigned)pixj[0], (unsigned)pixj[1], (unsigned)pixj[2], (unsigned)pixj[3]) : pixj[4];
+          const bool st = pj >= 0 && (r == 0 || fq == 0);
+          *(st ? p.b3 + (int64_t)pj * (C4 / 32) + q * 4 + wn : (unsigned*)g_blk_sink) = w;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 template <bool BWD, bool F16, bool MB = false, int HEAD = 0>
@@ -1469,6 +1938,37 @@ static int launch_block128(BlockParams& p, hipStream_t stream) {
   return 0;
 }
 
+// Tile height of the C = 128 kernels for this launch: 8 or 10 rows, whichever takes fewer workgroup-rounds x rows on
+// the chip's 256 CUs (one workgroup per CU).  A single-image launch is one of a pair — the step runs one chain per
+// image side by side — so its tiles count twice.  TDN_BLOCK128_TH=8 / 10 forces one.
+static int block128_th(const BlockParams& p) {
+  const char* e = getenv("TDN_BLOCK128_TH");
+  if (e && *e) return atoi(e) == 10 ? 10 : 8;
+  const int tx = ceil_div(p.W, 16);
+  const int k = p.N == 1 ? 2 : 1;
+  const int r8 = ceil_div(k * p.N * tx * ceil_div(p.H, 8), 256) * 8;
+  const int r10 = ceil_div(k * p.N * tx * ceil_div(p.H, 10), 256) * 10;
+  return r10 < r8 ? 10 : 8;
+}
+
+template <bool BWD, bool F16, bool MB = false>
+static int launch_block128t(BlockParams& p, hipStream_t stream) {
+  constexpr int lds = 163840;
+  static tdn_attr_once attr_once;
+  if (attr_once.need()) {
+    hipError_t e = hipFuncSetAttribute((const void*)bottleneck128t_kernel<BWD, F16, MB>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    TDN_CHECK(e == hipSuccess, "hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
+    attr_once.mark();
+  }
+  p.tiles_y = ceil_div(p.H, 10);
+  p.ntiles = p.N * p.tiles_x * p.tiles_y;
+  p.nwg_pad = (p.ntiles + 7) & ~7;
+  TDN_LAUNCH((bottleneck128t_kernel<BWD, F16, MB>), dim3(p.nwg_pad), dim3(512), lds, stream, p);
+  TDN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int tdn_bottleneck_supported(int H, int W, int C, int stride, int dilation) {
   return ((C == 64 || C == 128) && stride == 1 && dilation == 1 && H > 0 && W > 0) ? 1 : 0;
 }
@@ -1499,6 +1999,10 @@ extern "C" int tdn_bottleneck_fwd(const tdn_bottleneck_args* a, int dtype, void*
   p.sc1 = a->scale1; p.sh1 = a->shift1; p.sc2 = a->scale2; p.sh2 = a->shift2; p.sc3 = a->scale3; p.sh3 = a->shift3;
   p.b1 = (unsigned*)a->bits1; p.b2 = (unsigned*)a->bits2; p.b3 = (unsigned*)a->bits3;   // optional outputs
   if (a->C == 128) {
+    if (block128_th(p) == 10) {
+      if (dtype == TDN_F16) return launch_block128t<false, true>(p, (hipStream_t)stream);
+      return launch_block128t<false, false>(p, (hipStream_t)stream);
+    }
     if (dtype == TDN_F16) return launch_block128<false, true>(p, (hipStream_t)stream);
     return launch_block128<false, false>(p, (hipStream_t)stream);
   }
@@ -1515,6 +2019,10 @@ extern "C" int tdn_bottleneck_dgrad(const tdn_bottleneck_args* a, int dtype, voi
   if (mb) {
     TDN_CHECK(a->bits1 && a->bits2 && a->bits3, "bottleneck dgrad: all three bit planes or none");
     if (a->C == 128) {
+      if (block128_th(p) == 10) {
+        if (dtype == TDN_F16) return launch_block128t<true, true, true>(p, (hipStream_t)stream);
+        return launch_block128t<true, false, true>(p, (hipStream_t)stream);
+      }
       if (dtype == TDN_F16) return launch_block128<true, true, true>(p, (hipStream_t)stream);
       return launch_block128<true, false, true>(p, (hipStream_t)stream);
     }
@@ -1522,6 +2030,10 @@ extern "C" int tdn_bottleneck_dgrad(const tdn_bottleneck_args* a, int dtype, voi
     return launch_block64<true, false, true>(p, (hipStream_t)stream);
   }
   if (a->C == 128) {
+    if (block128_th(p) == 10) {
+      if (dtype == TDN_F16) return launch_block128t<true, true>(p, (hipStream_t)stream);
+      return launch_block128t<true, false>(p, (hipStream_t)stream);
+    }
     if (dtype == TDN_F16) return launch_block128<true, true>(p, (hipStream_t)stream);
     return launch_block128<true, false>(p, (hipStream_t)stream);
   }
