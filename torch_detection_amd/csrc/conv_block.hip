@@ -1939,15 +1939,17 @@ static int launch_block128(BlockParams& p, hipStream_t stream) {
 }
 
 // Tile height of the C = 128 kernels for this launch: 8 or 10 rows, whichever takes fewer workgroup-rounds x rows on
-// the chip's 256 CUs (one workgroup per CU).  A single-image launch is one of a pair — the step runs one chain per
-// image side by side — so its tiles count twice.  TDN_BLOCK128_TH=8 / 10 forces one.
+// the chip's 256 CUs (one workgroup per CU).  Only the launch's own tiles count: the two single-image launches of a
+// batch-2 step (one chain per image) do not run in lock-step — measured in the step, 8 and 10 rows are equal there
+// (525.7 vs 526.5 img/s) while a single image alone is 10 % faster with 8 rows; launches of two or more images
+// (R101 at 4 images per GPU: two chains of two; TDN_IMG_SPLIT_M below the layer2 size) take 10 rows and gain a third
+// (both images of 100 x 168: 57.4 -> 38.7 us).  TDN_BLOCK128_TH=8 / 10 forces one.
 static int block128_th(const BlockParams& p) {
   const char* e = getenv("TDN_BLOCK128_TH");
   if (e && *e) return atoi(e) == 10 ? 10 : 8;
   const int tx = ceil_div(p.W, 16);
-  const int k = p.N == 1 ? 2 : 1;
-  const int r8 = ceil_div(k * p.N * tx * ceil_div(p.H, 8), 256) * 8;
-  const int r10 = ceil_div(k * p.N * tx * ceil_div(p.H, 10), 256) * 10;
+  const int r8 = ceil_div(p.N * tx * ceil_div(p.H, 8), 256) * 8;
+  const int r10 = ceil_div(p.N * tx * ceil_div(p.H, 10), 256) * 10;
   return r10 < r8 ? 10 : 8;
 }
 
