@@ -26,10 +26,13 @@ Semantics of the gradient views: with a reducer attached the kernels OVERWRITE `
 (beta = 0) — gradient accumulation over several backward passes, or a module applied twice in one step, is not
 supported in this mode (use the plain autograd path, which accumulates as usual).
 """
+import os
+import weakref
+
 import torch
 import torch.distributed as dist
 
-from . import streams
+from . import functional, streams
 
 
 class GradReducer(object):
@@ -83,7 +86,6 @@ class GradReducer(object):
         #           weight-gradient groups launched): three of R50-FPN's four 32 MiB buckets start there and overlap
         #           layer1 and the tail of the pass, the last one follows from finish(): 509 img/s on one rank
         #   finish  all from finish() (no overlap): 505-510;   <n>: at the n-th stage (1, 2: as bad as ready)
-        import os
         self.launch_mode = os.environ.get('TDN_DP_LAUNCH', 'late')
         self.defer = self.launch_mode != 'ready'
         self._pending = None
@@ -259,8 +261,6 @@ def attach_reducer(modules, bucket_bytes=32 << 20, group=None, average=True, dty
         u.on_grads = _cb
     # the backward schedule tells the reducer when a stage's weight-gradient groups have been launched (held weakly:
     # a dropped reducer drops out of the hook list)
-    import weakref
-    from . import functional
     ref = weakref.ref(red)
 
     def _hook(n, nstages, _ref=ref):
